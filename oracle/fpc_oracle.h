@@ -1,0 +1,121 @@
+/*
+ * oracle/fpc_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain C++ (host, scalar, single-threaded) restatement of the reference algorithm for the
+ * MCTS.search hot path of jorr3/Alphazero-4-player-chess, written from the
+ * reference's behaviour, each function citing the reference file:line it follows.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product (alphazero-4-player-chess_amd/) never links, imports or calls it.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks every function below against
+ * golden vectors produced by the real reference compiled in the build container
+ * (oracle/_ref, recipe oracle/Makefile, generator oracle/gen_golden.py), for both the literal
+ * 8x8/2 snapshot and the 14x14/3 north-star size.
+ *
+ * Board sizes: square boards R x R with INV x INV cut corners (engine/board.h:22-24).
+ */
+#ifndef FPC_ORACLE_H_
+#define FPC_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_SQ 196   /* 14*14 */
+#define ORC_MAX_PL 32    /* capacity of one colour's piece list */
+#define ORC_NO_SQ 255
+
+/* piece byte: 0 = empty, else 0x80 | colour<<5 | type<<2   (engine/board.h:101-104)
+ * colour: RED 0, BLUE 1, YELLOW 2, GREEN 3; type: PAWN 0 .. KING 5 (engine/board.h:30-48) */
+typedef struct orc_board {
+  uint8_t sq[ORC_MAX_SQ];        /* location_to_piece_  [row*R+col]      engine/board.h:698 */
+  uint8_t pl[4][ORC_MAX_PL];     /* piece_list_ (square of each entry, list order) board.h:700 */
+  uint8_t plen[4];
+  uint8_t castle[4];             /* bit0 kingside, bit1 queenside          engine/board.h:702 */
+  uint8_t king[4];               /* king_locations_, ORC_NO_SQ if none     engine/board.h:705 */
+  uint8_t turn;                  /* turn_                                  engine/board.h:696 */
+  uint8_t pad[3];
+} orc_board;
+
+typedef struct orc_move {        /* chess::Move, engine/board.h:330-436 */
+  uint8_t from, to;
+  uint8_t capture;               /* standard_capture_ piece byte (0 none) */
+  uint8_t promo;                 /* promotion_piece_type_ (6 = NO_PIECE)   */
+  uint8_t rook_from, rook_to;    /* rook_move_ (ORC_NO_SQ none)            */
+  uint8_t init_rights;           /* 0x80 present | bit0 K | bit1 Q         */
+  uint8_t new_rights;
+} orc_move;
+
+/* evaluator seam == the reference's `neural_net(x) -> (logits, value)` (mcts.py:65-66):
+ * enc  [B,24,R,R] f32 (already rotated as the reference does), logits [B,A] f32, value [B] f32 */
+typedef void (*orc_eval_fn)(void *user, const float *enc, int B, float *logits, float *value);
+
+/* ---- geometry / codec (board.cpp:9-14, move.cpp:13-104) ---- */
+int orc_action_channels(int R);              /* 4R+4C+8 */
+int orc_action_size(int R);                  /* A_ch*R*R */
+int orc_is_legal_location(int R, int INV, int row, int col);
+int orc_move_plane(int R, int from, int to); /* action plane of (from,to) or -1 (GetIndex throws) */
+int orc_move_flat(int R, int from, int to);  /* GetFlatIndex, -1 if unmapped */
+int orc_flat_to_move(int R, int flat, int *from, int *to); /* Move(flat): to may be ORC_NO_SQ */
+
+/* ---- board construction ---- */
+/* Builds a board from per-colour ordered piece lists (square, type); this is the reference state
+ * AFTER its constructor has ordered piece_list_ (engine/board.cpp:1172-1248). */
+void orc_board_init(orc_board *b, int R, int turn);
+int  orc_board_add(orc_board *b, int R, int colour, int type, int sq); /* append to list */
+/* Restatement of the constructor's ordering: pieces given in dict insertion order are pushed
+ * through a std::unordered_map with the reference's hash (engine/board.h:229-237), iterated,
+ * and std::sort'ed with the reference comparator (engine/board.cpp:1209-1247). */
+void orc_board_from_dict(orc_board *b, int R, int turn, const uint8_t *sqs, const uint8_t *pieces,
+                         int n, const uint8_t *castle4 /* nullable */);
+
+/* ---- engine (all MUTATE piece-list order exactly like the reference) ---- */
+int  orc_pseudo_legal(orc_board *b, int R, int INV, orc_move *out, int cap);   /* board.cpp:846 */
+int  orc_legal_moves(orc_board *b, int R, int INV, orc_move *out, int cap);    /* board.cpp:94-118 */
+int  orc_game_result(orc_board *b, int R, int INV, int player /* -1 = turn */);/* board.cpp:891 */
+int  orc_is_king_in_check(const orc_board *b, int R, int INV, int colour);     /* board.cpp:941 */
+int  orc_is_attacked_by_team(const orc_board *b, int R, int INV, int team, int sq);
+int  orc_make_move(orc_board *b, int R, const orc_move *m);  /* 0 ok, -1 "piece missing" throw */
+int  orc_take_action_flat(orc_board *b, int R, int flat);    /* Move(flat)+MakeMove on b itself */
+int  orc_heuristic(const orc_board *b, int team);            /* engine/board.cpp:1263-1292 */
+
+/* ---- tensors ---- */
+/* GetEncodedStates (board.cpp:305-356): out [n,24,R,R] f32, rotated by boards[0].turn */
+void orc_encode(const orc_board *boards, int n, int R, float *out);
+/* index map of torch.rot90(x, k, (-2,-1)): out[i][j] = in[si][sj]; returns si*R+sj */
+int  orc_rot90_src(int R, int k, int i, int j);
+
+/* deterministic f32 exp used by BOTH the oracle and the HIP engine (spec in DESIGN.md) */
+float orc_expf(float x);
+/* softmax -> ParseActionspace -> mask -> renormalise (mcts.py:67-76) for one sample.
+ * legal_flat: ascending, deduplicated absolute flat indices. priors out (f32). returns
+ * 0 ok, 1 if the legal mass is 0/NaN (reference would expand every index and throw). */
+int  orc_policy_priors(const float *logits, int R, int turn0, const int *legal_flat, int n_legal,
+                       float *priors);
+
+/* ---- MCTS.search (mcts.py:17-43 + node.cpp) ---- */
+typedef struct orc_search_out {
+  int root_visits;       /* root N */
+  int n_children;
+  int terminated;        /* root was dropped from the search (Q5) */
+  int sims_done;         /* leaf evaluations + terminal backups performed for this game */
+} orc_search_out;
+/* boards are updated in place (piece-list order of the root state changes, as in the
+ * reference).  child_flat/child_visits/child_prior/child_w: [G][max_children].
+ * returns 0, or <0 on a reference-side throw (-2: selection failed, -3: NaN policy) */
+int orc_search(orc_board *boards, int G, int R, int INV, int sims, double Cpuct,
+               orc_eval_fn eval, void *user, orc_search_out *out, int max_children,
+               int *child_flat, int *child_visits, float *child_prior, double *child_w);
+
+/* built-in synthetic evaluators: 0 = zero, 1 = ramp */
+void orc_eval_zero(void *user, const float *enc, int B, float *logits, float *value);
+void orc_eval_ramp(void *user, const float *enc, int B, float *logits, float *value);
+typedef struct orc_eval_ctx { int R; } orc_eval_ctx;
+
+#ifdef __cplusplus
+}
+#endif
+#endif

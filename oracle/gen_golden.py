@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""oracle/gen_golden.py -- TEST INFRASTRUCTURE ONLY.
+
+Generates the golden vectors under tests/golden/ by RUNNING THE REAL REFERENCE
+(jorr3/Alphazero-4-player-chess, compiled by oracle/Makefile into oracle/_ref/{r8,r14}) together
+with its own Python files (mcts.py, four_player_chess_board.py, fen_parser.py, net.py) imported
+from /root/reference/src/py.  Runs only in the build container; the fixtures it writes are data
+(inputs + expected outputs), never reference source.
+
+    python oracle/gen_golden.py --size 8      # literal snapshot: 8x8, 2x2 corners
+    python oracle/gen_golden.py --size 14     # north-star size: 14x14, 3x3 corners
+
+`line_profiler_pycharm` (a PyCharm plugin the reference imports only for an identity-like
+@profile decorator, mcts.py:5) is replaced by a two-line stub written to a temp dir.
+"""
+import argparse
+import gzip
+import json
+import os
+import random
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = os.environ.get("FPC_REFERENCE", "/root/reference")
+
+
+def setup_imports(size):
+    stub = tempfile.mkdtemp(prefix="fpc_stub_")
+    with open(os.path.join(stub, "line_profiler_pycharm.py"), "w") as f:
+        f.write("def profile(fn):\n    return fn\n")
+    sys.path[:0] = [os.path.join(HERE, "_ref", "r%d" % size), stub, os.path.join(REF, "src", "py")]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, required=True, choices=[8, 14])
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    args = ap.parse_args()
+    setup_imports(args.size)
+
+    import torch
+    import alphazero_cpp as az
+    import start_fens
+    from fen_parser import parse_board_args_from_fen
+    from four_player_chess_board import FourPlayerChess
+    from mcts import MCTS
+
+    torch.set_num_threads(4)
+    R = az.Board.nRows()
+    INV = az.Board.invalidArea()
+    assert R == args.size
+    RR = R * R
+    A = az.Board.action_space_size
+    A_ch = az.Board.num_action_channels
+    fen = (start_fens.EIGHT_SIMPLE if R == 8 else start_fens.STANDARD).replace("\n", "")
+    start_args = parse_board_args_from_fen(fen, R)
+
+    def new_board(turn=None, l2p=None):
+        if l2p is None:
+            return FourPlayerChess(*parse_board_args_from_fen(fen, R))
+        return FourPlayerChess(turn, l2p)
+
+    def lists(b):
+        """piece_list_ per colour as [[sq, type], ...] in list order."""
+        out = []
+        for col in b.GetPieces():
+            out.append([[pp.GetLocation().GetRow() * R + pp.GetLocation().GetCol(),
+                         int(pp.GetPiece().GetPieceType())] for pp in col])
+        return out
+
+    def snapshot(b):
+        return {"turn": int(b.GetTurn().GetColor()), "pl": lists(b)}
+
+    def dict_order(l2p):
+        """insertion order of the python dict handed to the Board ctor: [[sq, colour, type], ...]"""
+        return [[k.GetRow() * R + k.GetCol(), int(v.GetColor()), int(v.GetPieceType())] for k, v in l2p.items()]
+
+    def legal_list(b):
+        """GetLegalMoves in reference order as [from, to, flat]; mutates b like the reference."""
+        out = []
+        for m in b.GetLegalMoves():
+            f, t = m.From(), m.To()
+            out.append([f.GetRow() * R + f.GetCol(), t.GetRow() * R + t.GetCol(), m.GetFlatIndex()])
+        return out
+
+    def enc_nonzero(t):
+        return [int(i) for i in torch.nonzero(t.flatten()).flatten().tolist()]
+
+    G = {"R": R, "INV": INV, "A": A, "A_ch": A_ch,
+         "state_space_size": az.Board.state_space_size,
+         "num_queen_moves": az.Move.num_queen_moves, "num_knight_moves": az.Move.num_knight_moves,
+         "fen": fen, "torch": torch.__version__}
+
+    # ---- 1. static: constructor order, start position, codec ----
+    b0 = new_board()
+    G["start"] = {"dict": dict_order(start_args[1]), "turn": int(start_args[0].GetColor()),
+                  "after_ctor": snapshot(b0)}
+    G["legal_loc"] = [[int(az.Board.IsLegalLocation(r, c)) for c in range(R)] for r in range(R)]
+    codec = []
+    rng = random.Random(1234)
+    for _ in range(400):
+        flat = rng.randrange(A)
+        m = az.Move(flat)
+        f, t = m.From(), m.To()
+        ent = [flat, f.GetRow() * R + f.GetCol(), t.GetRow() * R + t.GetCol()]
+        codec.append(ent)
+    G["codec_flat_to_move"] = codec   # BoardLocation() missing -> GetRow()*R+GetCol() of loc_=R*R
+
+    # ---- 2. random reachable positions (random playouts through the reference API) ----
+    def playout(seed, max_plies, record_every=1, take_children=False):
+        rng = random.Random(seed)
+        b = new_board()
+        recs = []
+        for ply in range(max_plies):
+            rec = {"before": snapshot(b)}
+            res = int(b.GetGameResult())
+            rec["result"] = res
+            rec["after_result"] = lists(b)
+            if res != 0:
+                recs.append(rec)
+                break
+            lm = legal_list(b)
+            rec["legal"] = lm
+            rec["after_legal"] = lists(b)
+            rec["enc"] = enc_nonzero(az.Board.GetEncodedState(b, "cpu"))
+            rec["check"] = [int(b.IsAttackedByPlayer(az.BoardLocation(0, 0), az.RED))]  # cheap smoke of a const fn
+            flats = sorted(set(x[2] for x in lm))
+            if take_children:
+                ch = []
+                for fl in flats:
+                    nb = b.TakeAction(az.Move(fl))
+                    ch.append([fl, snapshot(nb)])
+                rec["children"] = ch
+            pick = flats[rng.randrange(len(flats))]
+            rec["pick"] = pick
+            if ply % record_every == 0:
+                recs.append(rec)
+            else:
+                recs.append({"before": rec["before"], "result": res, "after_result": rec["after_result"],
+                             "legal": lm, "after_legal": rec["after_legal"], "pick": pick})
+            nb = b.TakeAction(az.Move(pick))
+            b = nb
+        return recs
+
+    n_games = 24 if R == 8 else 10
+    plies = 200 if R == 8 else 160
+    G["playouts"] = [playout(1000 + s, plies, record_every=1, take_children=(s < 2)) for s in range(n_games)]
+    n_term = sum(1 for g in G["playouts"] if g[-1]["result"] != 0)
+    print("playouts:", n_games, "terminal:", n_term, "positions:", sum(len(g) for g in G["playouts"]))
+
+    # ---- 3. batch encode with mixed turns (quirk Q6) ----
+    mixed = []
+    b = new_board()
+    rng = random.Random(77)
+    chain = [b]
+    for _ in range(7):
+        lm = legal_list(chain[-1])
+        flats = sorted(set(x[2] for x in lm))
+        chain.append(chain[-1].TakeAction(az.Move(flats[rng.randrange(len(flats))])))
+    order = [3, 0, 5, 2, 7, 1]
+    states = [chain[i] for i in order]
+    enc = az.Board.GetEncodedStates(states, "cpu")
+    G["batch_encode"] = {"states": [snapshot(s) for s in states], "enc": enc_nonzero(enc),
+                         "shape": list(enc.shape)}
+
+    # ---- 4. MCTS.search with synthetic evaluators ----
+    class Eval:
+        def __init__(self, kind):
+            self.kind = kind
+            self.device = "cpu"
+            self.w11 = (torch.arange(24 * RR) % 11).to(torch.float32).view(1, 24, R, R)
+            self.widx = ((torch.arange(24 * RR, dtype=torch.int64) * 2654435761) % (1 << 32)).view(1, 24, R, R)
+
+        def __call__(self, x):
+            B = x.shape[0]
+            if self.kind == "zero":
+                return torch.zeros(B, A), torch.zeros(B, 1)
+            if self.kind == "ramp":
+                logits = (-(torch.arange(A) % 7).to(torch.float32) / 8).repeat(B, 1)
+                v = (((x * self.w11).sum(dim=(1, 2, 3)) % 5) - 2) / 4
+                return logits, v.view(B, 1)
+            # integer-hash pseudo-net: exactly representable logits/values, a different pattern per position
+            h = ((x.to(torch.int64) * self.widx).sum(dim=(1, 2, 3))) % (1 << 32)          # [B]
+            i = torch.arange(A, dtype=torch.int64).view(1, A)
+            u = ((h.view(B, 1) * 2246822519 + i * 40503 + ((i * i) % 8191) * 69069) % (1 << 32)) >> 16   # 0..65535
+            if self.kind == "hash":
+                logits = u.to(torch.float32) / 8192.0 - 4.0
+            else:  # "hashinf": ~1/4 of the entries are -inf (exact zeros after softmax)
+                logits = torch.where((u % 4) == 0, torch.tensor(float("-inf")), torch.zeros(()))
+                logits = logits.to(torch.float32).expand(B, A).clone()
+                # never mask everything: entry with u%4==0 for all legal moves is astronomically unlikely
+            v = ((h % 9).to(torch.float32) - 4) / 4
+            return logits, v.view(B, 1)
+
+    def run_search(states, kind, sims, C=3.0, two_level=True):
+        margs = {"pool_size": 10, "C": C, "num_searches": sims}
+        mcts = MCTS(FourPlayerChess, Eval(kind), margs)
+        before = [snapshot(s) for s in states]
+        try:
+            roots = mcts.search(states)
+        except AssertionError:
+            roots = [s.GetRootNode() for s in states]
+        out = []
+        for r, s in zip(roots, states):
+            ch = []
+            for c in r.GetChildren():
+                ent = [c.GetMoveMade().GetFlatIndex(), c.GetVisitCount()]
+                if two_level:
+                    ent.append([[g.GetMoveMade().GetFlatIndex(), g.GetVisitCount()] for g in c.GetChildren()])
+                ch.append(ent)
+            out.append({"root_n": r.GetVisitCount(), "children": ch, "after": lists(s)})
+        return {"kind": kind, "sims": sims, "C": C, "before": before, "roots": out}
+
+    searches = []
+    for kind in ["zero", "ramp", "hash", "hashinf"]:
+        for sims in ([100, 400] if kind != "hashinf" else [100]):
+            if R == 14 and sims == 400 and kind in ("hash",):
+                continue
+            searches.append(run_search([new_board()], kind, sims))
+            print("search", kind, sims, "done")
+    # mixed-depth batch (Q6) : 6 states with different turns, shared batch
+    for kind in ["zero", "hash"]:
+        sts = [FourPlayerChess(c.GetTurn(), {pp.GetLocation(): pp.GetPiece() for col in c.GetPieces() for pp in col})
+               for c in [chain[i] for i in order]]
+        searches.append(run_search(sts, kind, 60))
+    # mid-game positions from the playouts (fresh boards rebuilt from recorded lists keep list order? no:
+    # the ctor reorders, so the fixture stores what the ctor produced in "before")
+    rng = random.Random(5)
+    mids = []
+    for gi in range(4):
+        game = G["playouts"][gi]
+        rec = game[min(len(game) - 2, 20 + 13 * gi)]
+        l2p = {}
+        for colour, col in enumerate(rec["before"]["pl"]):
+            for sq, typ in col:
+                l2p[az.BoardLocation(sq // R, sq % R)] = az.Piece(az.PlayerColor(colour), az.PieceType(typ))
+        mids.append(FourPlayerChess(az.Player(az.PlayerColor(rec["before"]["turn"])), l2p))
+    searches.append(run_search(mids, "hash", 80))
+    searches.append(run_search([FourPlayerChess(m.GetTurn(), {pp.GetLocation(): pp.GetPiece() for col in m.GetPieces() for pp in col}) for m in mids], "ramp", 80))
+    if R == 8:
+        # terminal cut-off position of SURVEY.md section 4 (Q5): R rook(4,3) R king(7,4) Y king(0,3) B king(4,0) G king(3,7)
+        def q5():
+            l2p = {az.BoardLocation(4, 3): az.Piece(az.RED, az.ROOK), az.BoardLocation(7, 4): az.Piece(az.RED, az.KING),
+                   az.BoardLocation(0, 3): az.Piece(az.YELLOW, az.KING), az.BoardLocation(4, 0): az.Piece(az.BLUE, az.KING),
+                   az.BoardLocation(3, 7): az.Piece(az.GREEN, az.KING)}
+            return FourPlayerChess(az.Player(az.RED), l2p)
+        searches.append(run_search([q5(), q5()], "zero", 100))
+        searches.append(run_search([q5(), new_board()], "hash", 100))
+    G["searches"] = searches
+
+    path = os.path.join(args.out, "ref_r%d.json.gz" % R)
+    os.makedirs(args.out, exist_ok=True)
+    with gzip.open(path, "wt") as f:
+        json.dump(G, f, separators=(",", ":"))
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

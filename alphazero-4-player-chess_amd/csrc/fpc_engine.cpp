@@ -1,0 +1,565 @@
+// fpc_engine.cpp -- host side of the C-ABI declared in include/fpc_engine.h.
+//
+// Owns every device allocation (tree SoA pools, board pools, staging), launches the kernels of
+// fpc_tree_kernels.h / fpc_nn_kernels.h on one HIP stream, and never computes game logic on the
+// host: positions are uploaded, processed by one wavefront each, and read back.  Compiled by hipcc
+// for gfx950 into libfpc_engine.so (the product).  The same file builds against the wavefront
+// emulator (-DFPC_EMUL, tests/emul/) for the CPU test-suite; that build has no NN and is never
+// loaded by the product modules.
+#include "fpc_tree_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#ifndef FPC_EMUL
+#include "fpc_nn.h"
+#endif
+
+using namespace fpc;
+
+namespace {
+std::string g_create_error;
+
+struct Timer {
+  hipEvent_t a = nullptr, b = nullptr;
+};
+}  // namespace
+
+struct fpc_engine {
+  fpc_config cfg{};
+  DevCfg dc{};
+  std::string err;
+  hipStream_t stream = nullptr;
+  // ---- batched board-op scratch
+  int cap_boards = 0;
+  fpc_board *d_boards = nullptr, *d_boards2 = nullptr;
+  fpc_move *d_moves = nullptr;
+  int *d_counts = nullptr, *d_results = nullptr, *d_err = nullptr, *d_player = nullptr, *d_flat = nullptr;
+  float *d_dense = nullptr;       // encode / mask output staging [cap_boards * max(24*RR, A)]
+  // ---- search
+  Tree t{};
+  std::vector<void *> allocs;
+  int G = 0;
+  double Cpuct = 0;
+  bool searching = false;
+  double *d_logtab = nullptr;
+  int *d_leaf_slot = nullptr;
+  float *d_enc_f32 = nullptr;     // [max_games,24,R,R]
+  fpc_board *d_roots = nullptr;   // staging [max_games]
+  int *d_rc_i = nullptr;          // root-children gather
+  float *d_rc_f = nullptr;
+  double *d_rc_d = nullptr;
+  int rc_cap = 0;
+  // ---- stats
+  bool timing = false;
+  fpc_stats stats{};
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+#ifndef FPC_EMUL
+  fpc::NN nn;
+#endif
+};
+
+namespace {
+
+int fail(fpc_engine *e, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (e) e->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIPCHK(e, call)                                                                        \
+  do {                                                                                         \
+    hipError_t _r = (call);                                                                    \
+    if (_r != hipSuccess) return fail(e, FPC_ENODEVICE, "%s failed: %s", #call, hipGetErrorString(_r)); \
+  } while (0)
+
+template <class T>
+int dalloc(fpc_engine *e, T **p, size_t count) {
+  void *q = nullptr;
+  if (hipMalloc(&q, count * sizeof(T)) != hipSuccess || !q) return fail(e, FPC_ENOMEM, "hipMalloc of %zu bytes failed", count * sizeof(T));
+  if (hipMemset(q, 0, count * sizeof(T)) != hipSuccess) return fail(e, FPC_ENODEVICE, "hipMemset failed");
+  e->allocs.push_back(q);
+  *p = (T *)q;
+  return 0;
+}
+
+int ensure_board_scratch(fpc_engine *e, int n) {
+  if (n <= e->cap_boards) return 0;
+  int cap = std::max(n, std::max(64, e->cap_boards * 2));
+  auto re = [&](auto **p, size_t count) -> int {
+    if (*p) { (void)hipFree(*p); e->allocs.erase(std::find(e->allocs.begin(), e->allocs.end(), (void *)*p)); *p = nullptr; }
+    return dalloc(e, p, count);
+  };
+  int r;
+  if ((r = re(&e->d_boards, cap))) return r;
+  if ((r = re(&e->d_boards2, cap))) return r;
+  if ((r = re(&e->d_moves, (size_t)cap * FPC_MAX_MOVES))) return r;
+  if ((r = re(&e->d_counts, cap))) return r;
+  if ((r = re(&e->d_results, cap))) return r;
+  if ((r = re(&e->d_err, cap))) return r;
+  if ((r = re(&e->d_player, cap))) return r;
+  if ((r = re(&e->d_flat, cap))) return r;
+  if ((r = re(&e->d_dense, (size_t)cap * std::max(24 * e->dc.RR, e->dc.A)))) return r;
+  e->cap_boards = cap;
+  return 0;
+}
+
+int check_boards(fpc_engine *e, const fpc_board *b, int n) {
+  for (int i = 0; i < n; ++i) {
+    for (int c = 0; c < 4; ++c) {
+      if (b[i].castle[c]) return fail(e, FPC_EUNSUPPORTED, "board %d: castling rights are set; the device path supports only the all-false rights the reference's FEN path produces (fen_parser.py:137-170)", i);
+      if (b[i].plen[c] > FPC_MAX_PL) return fail(e, FPC_EINVAL, "board %d: piece list longer than %d", i, FPC_MAX_PL);
+    }
+    if (b[i].turn > 3) return fail(e, FPC_EINVAL, "board %d: bad turn", i);
+  }
+  return 0;
+}
+
+int err_to_status(fpc_engine *e, const std::vector<int> &errs, const char *what) {
+  for (size_t i = 0; i < errs.size(); ++i) {
+    const int x = errs[i];
+    if (!x) continue;
+    if (x & ERR_MOVE) return fail(e, FPC_EMOVE, "%s %zu: piece missing for move (engine/board.cpp:1046-1054)", what, i);
+    if (x & ERR_SELECT) return fail(e, FPC_ESELECT, "%s %zu: Failed to select a child. (node.cpp:72-75)", what, i);
+    if (x & ERR_POLICY) return fail(e, FPC_EPOLICY, "%s %zu: legal policy mass is zero/NaN (reference expands every index and throws)", what, i);
+    return fail(e, FPC_ECAPACITY, "%s %zu: capacity exceeded (bits %d: moves>%d / node pool / board pool)", what, i, x, FPC_MAX_MOVES);
+  }
+  return 0;
+}
+
+int run_board_ops(fpc_engine *e, fpc_board *boards, int n, int ops, const int *player, const int *flat) {
+  int r;
+  if ((r = ensure_board_scratch(e, n))) return r;
+  HIPCHK(e, hipMemcpyAsync(e->d_boards, boards, (size_t)n * sizeof(fpc_board), hipMemcpyHostToDevice, e->stream));
+  if (player) HIPCHK(e, hipMemcpyAsync(e->d_player, player, (size_t)n * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  if (flat) HIPCHK(e, hipMemcpyAsync(e->d_flat, flat, (size_t)n * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  FPC_LAUNCH(k_board_ops, n, 64, e->stream, e->dc, e->d_boards, n, ops, player ? e->d_player : (const int *)nullptr,
+             flat ? e->d_flat : (const int *)nullptr, e->d_moves, e->d_counts, e->d_results, e->d_err);
+  HIPCHK(e, hipGetLastError());
+  return 0;
+}
+
+int fetch_errs(fpc_engine *e, int n, const char *what) {
+  std::vector<int> errs(n);
+  HIPCHK(e, hipMemcpyAsync(errs.data(), e->d_err, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return err_to_status(e, errs, what);
+}
+
+struct LocHash {   // std::hash<chess::BoardLocation>, engine/board.h:229-237
+  int R;
+  size_t operator()(uint8_t s) const {
+    size_t h = 14479 + 14593 * (size_t)(int8_t)(s / R);
+    h += 24439 * (size_t)(int8_t)(s % R);
+    return h;
+  }
+};
+
+void stage_begin(fpc_engine *e, int i) {
+  if (e->timing) (void)hipEventRecord(e->ev[i], e->stream);
+}
+void stage_end(fpc_engine *e, int i, double *acc) {
+  if (!e->timing) return;
+  (void)hipEventRecord(e->ev[i + 1], e->stream);
+  (void)hipEventSynchronize(e->ev[i + 1]);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]);
+  *acc += ms;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fpc_abi_version(void) { return 1; }
+
+const char *fpc_last_error(const fpc_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int fpc_num_action_channels(int R) { return 8 * R + 8; }
+int fpc_action_space_size(int R) { return (8 * R + 8) * R * R; }
+int fpc_is_legal_location(int R, int INV, int row, int col) {
+  const int mx = R - 1;
+  if (row < 0 || row > mx || col < 0 || col > mx) return 0;
+  const bool cc = col < INV || col > mx - INV;
+  return !(cc && (row < INV || row > mx - INV));
+}
+int fpc_move_flat_index(int R, int from, int to) {
+  if (from < 0 || to < 0 || from >= R * R || to >= R * R || from == to) return -1;
+  const int dy = to / R - from / R, dx = to % R - from % R;
+  const int ay = std::abs(dy), ax = std::abs(dx);
+  const bool queen = dx == 0 || dy == 0 || ax == ay;
+  const bool knight = (ax == 1 && ay == 2) || (ax == 2 && ay == 1);
+  if (!queen && !knight) return -1;
+  DevCfg c{R, 0, R * R, 8 * R + 8, (8 * R + 8) * R * R};
+  return move_plane(c, from, to) * R * R + from;
+}
+int fpc_flat_to_move(int R, int flat, int *from, int *to) {
+  DevCfg c{R, 0, R * R, 8 * R + 8, (8 * R + 8) * R * R};
+  if (flat < 0 || flat >= c.A) return FPC_EINVAL;
+  *to = flat_to(c, flat, from);
+  return 0;
+}
+
+int fpc_board_from_dict(fpc_board *out, int R, int turn, const uint8_t *sq, const uint8_t *piece, int n,
+                        const uint8_t *castle4) {
+  if (!out || R < 4 || R * R > FPC_MAX_SQ || turn < 0 || turn > 3 || n < 0) return FPC_EINVAL;
+  memset(out, 0, sizeof(*out));
+  for (int c = 0; c < 4; ++c) out->king[c] = FPC_NO_SQ;
+  out->turn = (uint8_t)turn;
+  if (castle4) for (int c = 0; c < 4; ++c) out->castle[c] = castle4[c] & 3;
+  // Same container, hash and insertion sequence as the reference constructor sees (pybind11's dict
+  // -> unordered_map caster reserves, then emplaces in dict order), so iteration order -- which
+  // the reference bakes into piece_list_ (engine/board.cpp:1209-1223) -- is reproduced.
+  std::unordered_map<uint8_t, uint8_t, LocHash> m(0, LocHash{R});
+  m.reserve((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    if (sq[i] >= R * R || !(piece[i] & 0x80)) return FPC_EINVAL;
+    m.emplace(sq[i], piece[i]);
+  }
+  std::vector<std::pair<uint8_t, uint8_t>> lists[4];
+  for (const auto &it : m) {
+    out->sq[it.first] = it.second;
+    const int col = (it.second >> 5) & 3;
+    lists[col].push_back({it.first, it.second});
+    if (((it.second >> 2) & 7) == KING) out->king[col] = it.first;
+  }
+  static const int score[8] = {1, 2, 3, 4, 5, 0, 0, 0};   // piece_move_order_scores, engine/board.cpp:1230-1236
+  for (int c = 0; c < 4; ++c) {
+    std::sort(lists[c].begin(), lists[c].end(), [](const std::pair<uint8_t, uint8_t> &a, const std::pair<uint8_t, uint8_t> &b) {
+      return score[(a.second >> 2) & 7] < score[(b.second >> 2) & 7];
+    });
+    if (lists[c].size() > FPC_MAX_PL) return FPC_ECAPACITY;
+    out->plen[c] = (uint8_t)lists[c].size();
+    for (size_t i = 0; i < lists[c].size(); ++i) out->pl[c][i] = lists[c][i].first;
+  }
+  return 0;
+}
+
+int fpc_board_heuristic(const fpc_board *b, int team) {   // engine/board.cpp:1263-1292
+  static const int val[8] = {1, 3, 3, 5, 9, 0, 0, 0};
+  int h = 0;
+  for (int c = 0; c < 4; ++c)
+    for (int i = 0; i < b->plen[c] && i < FPC_MAX_PL; ++i) {
+      const uint8_t p = b->sq[b->pl[c][i]];
+      if (!(p & 0x80)) continue;
+      const int ty = (p >> 2) & 7;
+      if (ty == KING) continue;
+      h += (((p >> 5) & 1) == team) ? val[ty] : -val[ty];
+    }
+  return h;
+}
+
+int fpc_create(const fpc_config *cfg, fpc_engine **out) {
+  if (!cfg || !out) return fail(nullptr, FPC_EINVAL, "null argument");
+  const int R = cfg->board_size, INV = cfg->invalid_area;
+  if (R < 6 || R > 14 || (R & 1) || INV < 1 || 2 * INV >= R) return fail(nullptr, FPC_EINVAL, "unsupported board %dx%d/%d", R, R, INV);
+  if (cfg->max_games < 1 || cfg->max_sims < 1) return fail(nullptr, FPC_EINVAL, "max_games/max_sims must be positive");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device || cfg->device < 0)
+    return fail(nullptr, FPC_ENODEVICE, "no HIP device %d (found %d): this engine has no CPU path", cfg->device, ndev);
+  if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, FPC_ENODEVICE, "hipSetDevice(%d) failed", cfg->device);
+  fpc_engine *e = new fpc_engine();
+  e->cfg = *cfg;
+  if (e->cfg.avg_children <= 0) e->cfg.avg_children = 96;
+  e->dc = DevCfg{R, INV, R * R, 8 * R + 8, (8 * R + 8) * R * R};
+  int r = 0;
+  auto bail = [&](int code) { g_create_error = e->err; fpc_destroy(e); return code; };
+  if (hipStreamCreate(&e->stream) != hipSuccess) { e->err = "hipStreamCreate failed"; return bail(FPC_ENODEVICE); }
+  for (auto &ev : e->ev) (void)hipEventCreate(&ev);
+  const int Gm = cfg->max_games;
+  Tree &t = e->t;
+  t.node_cap = 1 + cfg->max_sims * e->cfg.avg_children;
+  t.board_cap = cfg->max_sims + 2;
+  const size_t nn = (size_t)Gm * t.node_cap;
+  if ((r = dalloc(e, &t.N, nn)) || (r = dalloc(e, &t.W, nn)) || (r = dalloc(e, &t.P, nn)) || (r = dalloc(e, &t.mv, nn)) ||
+      (r = dalloc(e, &t.parent, nn)) || (r = dalloc(e, &t.child0, nn)) || (r = dalloc(e, &t.nch, nn)) ||
+      (r = dalloc(e, &t.bslot, nn)) || (r = dalloc(e, &t.boards, (size_t)Gm * t.board_cap)) ||
+      (r = dalloc(e, &t.nnodes, Gm)) || (r = dalloc(e, &t.nboards, Gm)) || (r = dalloc(e, &t.alive, Gm)) ||
+      (r = dalloc(e, &t.sims_done, Gm)) || (r = dalloc(e, &t.err, Gm)) || (r = dalloc(e, &t.leaf_node, Gm)) ||
+      (r = dalloc(e, &t.leaf_turn, Gm)) || (r = dalloc(e, &t.nlegal, Gm)) ||
+      (r = dalloc(e, &t.legal, (size_t)Gm * FPC_MAX_MOVES)) || (r = dalloc(e, &e->d_leaf_slot, Gm)) ||
+      (r = dalloc(e, &e->d_enc_f32, (size_t)Gm * 24 * e->dc.RR)) || (r = dalloc(e, &e->d_roots, Gm)) ||
+      (r = dalloc(e, &e->d_logtab, (size_t)cfg->max_sims + 16)))
+    return bail(r);
+  {
+    // log(sqrt(N_parent)) (node.cpp:53-54) tabulated with the HOST libm so that the device PUCT
+    // sees exactly the bits the reference's std::log produces; +,*,/,sqrt are IEEE on both sides.
+    std::vector<double> lt((size_t)cfg->max_sims + 16);
+    for (size_t i = 0; i < lt.size(); ++i) lt[i] = i == 0 ? 0.0 : std::log(std::sqrt((double)i));
+    if (hipMemcpy(e->d_logtab, lt.data(), lt.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+      e->err = "logtab upload failed";
+      return bail(FPC_ENODEVICE);
+    }
+  }
+#ifndef FPC_EMUL
+  if ((r = e->nn.init(e->dc, Gm, cfg->nn_dtype, e->stream, &e->err))) return bail(r);
+#endif
+  *out = e;
+  return 0;
+}
+
+void fpc_destroy(fpc_engine *e) {
+  if (!e) return;
+#ifndef FPC_EMUL
+  e->nn.destroy();
+#endif
+  for (void *p : e->allocs) (void)hipFree(p);
+  for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+// ------------------------------------------------------------------------------------------------
+int fpc_boards_legal_moves(fpc_engine *e, fpc_board *boards, int n, fpc_move *moves, int *counts) {
+  if (!e || !boards || !moves || !counts || n < 0) return fail(e, FPC_EINVAL, "bad argument");
+  if (n == 0) return 0;
+  int r;
+  if ((r = check_boards(e, boards, n))) return r;
+  if ((r = run_board_ops(e, boards, n, OP_LEGAL, nullptr, nullptr))) return r;
+  HIPCHK(e, hipMemcpyAsync(boards, e->d_boards, (size_t)n * sizeof(fpc_board), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipMemcpyAsync(counts, e->d_counts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipMemcpyAsync(moves, e->d_moves, (size_t)n * FPC_MAX_MOVES * sizeof(fpc_move), hipMemcpyDeviceToHost, e->stream));
+  return fetch_errs(e, n, "board");
+}
+
+int fpc_boards_game_result(fpc_engine *e, fpc_board *boards, int n, const int *player, int *results) {
+  if (!e || !boards || !results || n < 0) return fail(e, FPC_EINVAL, "bad argument");
+  if (n == 0) return 0;
+  int r;
+  if ((r = check_boards(e, boards, n))) return r;
+  if ((r = run_board_ops(e, boards, n, OP_RESULT, player, nullptr))) return r;
+  HIPCHK(e, hipMemcpyAsync(boards, e->d_boards, (size_t)n * sizeof(fpc_board), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipMemcpyAsync(results, e->d_results, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  return fetch_errs(e, n, "board");
+}
+
+int fpc_boards_take_action(fpc_engine *e, const fpc_board *boards, const int *flat, int n, fpc_board *out) {
+  if (!e || !boards || !flat || !out || n < 0) return fail(e, FPC_EINVAL, "bad argument");
+  if (n == 0) return 0;
+  int r;
+  if ((r = check_boards(e, boards, n))) return r;
+  for (int i = 0; i < n; ++i)
+    if (flat[i] < 0 || flat[i] >= e->dc.A) return fail(e, FPC_EINVAL, "flat index %d out of range", flat[i]);
+  if ((r = run_board_ops(e, const_cast<fpc_board *>(boards), n, OP_TAKE, nullptr, flat))) return r;
+  HIPCHK(e, hipMemcpyAsync(out, e->d_boards, (size_t)n * sizeof(fpc_board), hipMemcpyDeviceToHost, e->stream));
+  return fetch_errs(e, n, "board");
+}
+
+int fpc_boards_encode(fpc_engine *e, const fpc_board *boards, int n, float *out_host) {
+  if (!e || !boards || !out_host || n < 0) return fail(e, FPC_EINVAL, "bad argument");
+  if (n == 0) return 0;
+  int r;
+  if ((r = check_boards(e, boards, n))) return r;
+  if ((r = ensure_board_scratch(e, n))) return r;
+  HIPCHK(e, hipMemcpyAsync(e->d_boards, boards, (size_t)n * sizeof(fpc_board), hipMemcpyHostToDevice, e->stream));
+  FPC_LAUNCH(k_encode, n, 64, e->stream, e->dc, (const fpc_board *)e->d_boards, 1, (const int *)nullptr,
+             (const int *)nullptr, n, 0, e->d_dense, (uint16_t *)nullptr, (uint16_t)0, (int)boards[0].turn);
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipMemcpyAsync(out_host, e->d_dense, (size_t)n * 24 * e->dc.RR * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+int fpc_boards_legal_mask(fpc_engine *e, fpc_board *boards, int n, float *out_host) {
+  if (!e || !boards || !out_host || n < 0) return fail(e, FPC_EINVAL, "bad argument");
+  if (n == 0) return 0;
+  int r;
+  if ((r = check_boards(e, boards, n))) return r;
+  if ((r = run_board_ops(e, boards, n, OP_LEGAL, nullptr, nullptr))) return r;
+  FPC_LAUNCH(k_mask_from_moves, n, 64, e->stream, e->dc, (const fpc_move *)e->d_moves, (const int *)e->d_counts, n, e->d_dense);
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipMemcpyAsync(boards, e->d_boards, (size_t)n * sizeof(fpc_board), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipMemcpyAsync(out_host, e->d_dense, (size_t)n * e->dc.A * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  return fetch_errs(e, n, "board");
+}
+
+// ------------------------------------------------------------------------------------------------
+int fpc_search_begin(fpc_engine *e, const fpc_board *roots, int n_games, double c_puct) {
+  if (!e || !roots || n_games < 1) return fail(e, FPC_EINVAL, "bad argument");
+  if (n_games > e->cfg.max_games) return fail(e, FPC_EINVAL, "n_games %d > max_games %d", n_games, e->cfg.max_games);
+  int r;
+  if ((r = check_boards(e, roots, n_games))) return r;
+  e->G = n_games;
+  e->Cpuct = c_puct;
+  HIPCHK(e, hipMemcpyAsync(e->d_roots, roots, (size_t)n_games * sizeof(fpc_board), hipMemcpyHostToDevice, e->stream));
+  FPC_LAUNCH(k_search_init, n_games, 64, e->stream, e->t, n_games, (const fpc_board *)e->d_roots);
+  HIPCHK(e, hipGetLastError());
+  e->searching = true;
+  return 0;
+}
+
+static int launch_select(fpc_engine *e) {
+  stage_begin(e, 0);
+  FPC_LAUNCH(k_select, e->G, 64, e->stream, e->dc, e->t, e->G, e->Cpuct, (const double *)e->d_logtab);
+  FPC_LAUNCH(k_leaf_slots, (e->G + 63) / 64, 64, e->stream, e->t, e->G, e->d_leaf_slot);
+  return 0;
+}
+
+int fpc_search_select(fpc_engine *e, int *n_live, const float **enc_dev) {
+  if (!e || !e->searching) return fail(e, FPC_ESTATE, "fpc_search_begin has not been called");
+  launch_select(e);
+  FPC_LAUNCH(k_encode, e->G, 64, e->stream, e->dc, (const fpc_board *)e->t.boards, e->t.board_cap,
+             (const int *)e->d_leaf_slot, (const int *)e->t.leaf_turn, e->G, 0, e->d_enc_f32, (uint16_t *)nullptr,
+             (uint16_t)0, -1);
+  HIPCHK(e, hipGetLastError());
+  stage_end(e, 0, &e->stats.ms_select);
+  e->stats.launches_select++;
+  std::vector<int> slots(e->G);
+  HIPCHK(e, hipMemcpyAsync(slots.data(), e->d_leaf_slot, (size_t)e->G * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  int live = 0;
+  for (int s : slots) live += s >= 0;
+  if (n_live) *n_live = live;
+  if (enc_dev) *enc_dev = e->d_enc_f32;
+  return 0;
+}
+
+int fpc_search_expand(fpc_engine *e, const float *logits_dev, const float *value_dev) {
+  if (!e || !e->searching) return fail(e, FPC_ESTATE, "fpc_search_begin has not been called");
+  if (!logits_dev || !value_dev) return fail(e, FPC_EINVAL, "null logits/value");
+  stage_begin(e, 2);
+  FPC_LAUNCH(k_expand, e->G, 64, e->stream, e->dc, e->t, e->G, logits_dev, value_dev);
+  HIPCHK(e, hipGetLastError());
+  stage_end(e, 2, &e->stats.ms_expand);
+  e->stats.launches_expand++;
+  return 0;
+}
+
+int fpc_search_run(fpc_engine *e, int sims) {
+  if (!e || !e->searching) return fail(e, FPC_ESTATE, "fpc_search_begin has not been called");
+  if (sims < 0 || sims > e->cfg.max_sims) return fail(e, FPC_EINVAL, "sims %d > max_sims %d", sims, e->cfg.max_sims);
+#ifdef FPC_EMUL
+  return fail(e, FPC_EWEIGHTS, "the internal ResNet exists only in the gfx950 build");
+#else
+  if (!e->nn.loaded) return fail(e, FPC_EWEIGHTS, "fpc_load_weights has not been called");
+  for (int s = 0; s < sims; ++s) {
+    launch_select(e);
+    FPC_LAUNCH(k_encode, e->G, 64, e->stream, e->dc, (const fpc_board *)e->t.boards, e->t.board_cap,
+               (const int *)e->d_leaf_slot, (const int *)e->t.leaf_turn, e->G, 1, (float *)nullptr, e->nn.input16(),
+               e->nn.one16(), -1);
+    stage_end(e, 0, &e->stats.ms_select);
+    stage_begin(e, 1);
+    int r = e->nn.forward(e->G, &e->err);
+    if (r) return r;
+    stage_end(e, 1, &e->stats.ms_nn);
+    stage_begin(e, 2);
+    FPC_LAUNCH(k_expand, e->G, 64, e->stream, e->dc, e->t, e->G, (const float *)e->nn.logits(), (const float *)e->nn.value());
+    stage_end(e, 2, &e->stats.ms_expand);
+    e->stats.launches_select++; e->stats.launches_nn++; e->stats.launches_expand++;
+  }
+  HIPCHK(e, hipGetLastError());
+  return 0;
+#endif
+}
+
+int fpc_search_results(fpc_engine *e, fpc_board *roots_out, int *root_visits, int *n_children, int *sims_done,
+                       int max_children, int *child_flat, int *child_visits, float *child_prior,
+                       double *child_value_sum) {
+  if (!e || !e->searching) return fail(e, FPC_ESTATE, "fpc_search_begin has not been called");
+  if (max_children < 0) return fail(e, FPC_EINVAL, "bad max_children");
+  const int G = e->G;
+  int r;
+  const size_t need = (size_t)G * std::max(max_children, 1);
+  if ((int)need > e->rc_cap) {
+    if ((r = dalloc(e, &e->d_rc_i, need * 2 + (size_t)G * 3)) || (r = dalloc(e, &e->d_rc_f, need)) || (r = dalloc(e, &e->d_rc_d, need))) return r;
+    e->rc_cap = (int)need;
+  }
+  int *d_flat = e->d_rc_i, *d_vis = e->d_rc_i + need, *d_meta = e->d_rc_i + 2 * need;
+  FPC_LAUNCH(k_root_children, G, 64, e->stream, e->t, G, max_children, d_flat, d_vis, e->d_rc_f, e->d_rc_d, d_meta, e->d_roots);
+  HIPCHK(e, hipGetLastError());
+  std::vector<int> meta((size_t)G * 3), errs(G);
+  HIPCHK(e, hipMemcpyAsync(meta.data(), d_meta, meta.size() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipMemcpyAsync(errs.data(), e->t.err, (size_t)G * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  if (roots_out) HIPCHK(e, hipMemcpyAsync(roots_out, e->d_roots, (size_t)G * sizeof(fpc_board), hipMemcpyDeviceToHost, e->stream));
+  if (child_flat) HIPCHK(e, hipMemcpyAsync(child_flat, d_flat, need * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  if (child_visits) HIPCHK(e, hipMemcpyAsync(child_visits, d_vis, need * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  if (child_prior) HIPCHK(e, hipMemcpyAsync(child_prior, e->d_rc_f, need * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  if (child_value_sum) HIPCHK(e, hipMemcpyAsync(child_value_sum, e->d_rc_d, need * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  uint64_t sims = 0, nodes = 0;
+  for (int g = 0; g < G; ++g) {
+    if (root_visits) root_visits[g] = meta[(size_t)g * 3 + 0];
+    if (n_children) n_children[g] = meta[(size_t)g * 3 + 1];
+    if (sims_done) sims_done[g] = meta[(size_t)g * 3 + 2];
+    sims += (uint64_t)meta[(size_t)g * 3 + 2];
+  }
+  (void)nodes;
+  e->stats.sims += sims;
+  return err_to_status(e, errs, "game");
+}
+
+int fpc_search_grandchildren(fpc_engine *e, int game, int child_idx, int max_children, int *n, int *flat, int *visits) {
+  if (!e || !e->searching || game < 0 || game >= e->G || !n) return fail(e, FPC_EINVAL, "bad argument");
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  const size_t nb = (size_t)game * e->t.node_cap;
+  int c0 = -1;
+  uint16_t nc = 0;
+  HIPCHK(e, hipMemcpy(&c0, e->t.child0 + nb, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(e, hipMemcpy(&nc, e->t.nch + nb, sizeof(uint16_t), hipMemcpyDeviceToHost));
+  if (c0 < 0 || child_idx < 0 || child_idx >= nc) return fail(e, FPC_EINVAL, "no such root child");
+  const size_t ch = nb + c0 + child_idx;
+  int g0 = -1;
+  uint16_t gn = 0;
+  HIPCHK(e, hipMemcpy(&g0, e->t.child0 + ch, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(e, hipMemcpy(&gn, e->t.nch + ch, sizeof(uint16_t), hipMemcpyDeviceToHost));
+  if (g0 < 0) { *n = 0; return 0; }
+  *n = gn;
+  const int k = std::min<int>(gn, max_children);
+  std::vector<uint16_t> mv(k);
+  HIPCHK(e, hipMemcpy(mv.data(), e->t.mv + nb + g0, (size_t)k * sizeof(uint16_t), hipMemcpyDeviceToHost));
+  if (visits) HIPCHK(e, hipMemcpy(visits, e->t.N + nb + g0, (size_t)k * sizeof(int), hipMemcpyDeviceToHost));
+  if (flat) for (int i = 0; i < k; ++i) flat[i] = mv[i];
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+int fpc_load_weights(fpc_engine *e, const void *blob, uint64_t nbytes) {
+  if (!e || !blob) return fail(e, FPC_EINVAL, "bad argument");
+#ifdef FPC_EMUL
+  (void)nbytes;
+  return fail(e, FPC_EWEIGHTS, "the internal ResNet exists only in the gfx950 build");
+#else
+  return e->nn.load(blob, nbytes, &e->err);
+#endif
+}
+
+int fpc_nn_forward(fpc_engine *e, const float *enc_dev, int n, float *logits_dev, float *value_dev) {
+  if (!e || !enc_dev || !logits_dev || !value_dev) return fail(e, FPC_EINVAL, "bad argument");
+#ifdef FPC_EMUL
+  (void)n;
+  return fail(e, FPC_EWEIGHTS, "the internal ResNet exists only in the gfx950 build");
+#else
+  if (!e->nn.loaded) return fail(e, FPC_EWEIGHTS, "fpc_load_weights has not been called");
+  if (n < 1 || n > e->cfg.max_games) return fail(e, FPC_EINVAL, "n out of range");
+  return e->nn.forward_external(enc_dev, n, logits_dev, value_dev, &e->err);
+#endif
+}
+
+int fpc_stats_get(fpc_engine *e, fpc_stats *out) {
+  if (!e || !out) return FPC_EINVAL;
+  *out = e->stats;
+  return 0;
+}
+int fpc_stats_reset(fpc_engine *e) {
+  if (!e) return FPC_EINVAL;
+  e->stats = fpc_stats{};
+  return 0;
+}
+int fpc_set_timing(fpc_engine *e, int enabled) {
+  if (!e) return FPC_EINVAL;
+  e->timing = enabled != 0;
+  return 0;
+}
+void *fpc_stream(fpc_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+}  // extern "C"

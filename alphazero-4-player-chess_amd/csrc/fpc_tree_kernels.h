@@ -1,0 +1,930 @@
+// fpc_tree_kernels.h -- CDNA4 kernels for the tree side of MCTS.search: one 64-lane wavefront per
+// concurrent game (block = 1 wave, grid = games), board state staged in LDS.
+//
+//   k_board_ops   batched Board::GetLegalMoves / GetGameResult / TakeAction / encode / mask
+//   k_select      Node::ChooseLeaf: PUCT descent (wave argmax), lazy leaf-board materialisation,
+//                 GetGameResult + GetLegalMoves on the leaf, terminal backup        (node.cpp:19-78)
+//   k_encode      Board::GetEncodedStates incl. the batch-wide rot90                 (board.cpp:305-356)
+//   k_expand      softmax / ParseActionspace / mask / renormalise, BackpropagateNodes, ExpandNodes
+//                                                                                    (mcts.py:67-89)
+//
+// Reference semantics (file:line relative to /root/reference/src/cpp) are restated per function.
+// Nothing here is translated from the reference: its board is a pointer-rich mailbox + std::vector
+// piece lists walked serially; here one wave works on a 288-byte LDS image, (piece,direction)
+// slots are walked by separate lanes, every pseudo-legal move is legality-tested by its own lane on
+// a *virtual* post-move board (no make/undo), and the piece-list reorderings that the reference's
+// make/undo loops cause (observable through GetGameResult) are applied in closed form.
+#pragma once
+#include "fpc_platform.h"
+#include "../../include/fpc_engine.h"
+
+namespace fpc {
+
+enum { PAWN = 0, KNIGHT = 1, BISHOP = 2, ROOK = 3, QUEEN = 4, KING = 5 };
+
+struct DevCfg {
+  int R, INV, RR, A_ch, A;
+};
+
+// error bits accumulated per game / per board (host maps them to fpc_status)
+enum { ERR_SELECT = 1, ERR_POLICY = 2, ERR_CAP_MOVES = 4, ERR_CAP_NODES = 8, ERR_MOVE = 16, ERR_CAP_BOARDS = 32 };
+
+// ---- per-game tree storage (SoA, one contiguous region per game) -------------------------------
+struct Tree {
+  int *N;            // visit_count                     node.h:70
+  double *W;         // value_sum                       node.h:76
+  float *P;          // prior (f32 -> double on use)    node.h:75, mcts.py:87
+  uint16_t *mv;      // move_made as flat index         node.h:74
+  int *parent;       // -1 for root                     node.h:73
+  int *child0;       // first child (children contiguous, ascending flat), -1 = not expanded  node.h:78
+  uint16_t *nch;
+  int *bslot;        // board-pool slot of this node's state, -1 = not materialised yet
+  fpc_board *boards; // board pool
+  int node_cap, board_cap;
+  // per game scalars
+  int *nnodes, *nboards, *alive, *sims_done, *err;
+  int *leaf_node;    // leaf chosen this step (-1: none)
+  int *leaf_turn;
+  int *nlegal;
+  uint16_t *legal;   // [G][FPC_MAX_MOVES] ascending unique flat indices of the leaf's legal moves
+};
+
+// ---- LDS image of one wave --------------------------------------------------------------------
+struct __attribute__((aligned(16))) WaveLds {
+  fpc_board b;                         // 288 B
+  uint8_t mfrom[FPC_MAX_MOVES];
+  uint8_t mto[FPC_MAX_MOVES];
+  uint8_t mcap[FPC_MAX_MOVES];
+  uint8_t mflag[FPC_MAX_MOVES];        // bit0 legal, bit1 promotion (reference emits 4 variants)
+  uint16_t lflat[FPC_MAX_MOVES];       // flat index of legal moves, reference order
+  uint16_t lsorted[FPC_MAX_MOVES];     // ascending
+  uint8_t lidx[FPC_MAX_MOVES];         // pseudo-move index of k-th legal move
+  float pri[FPC_MAX_MOVES];
+  uint16_t poff[FPC_MAX_PL + 1];       // first pseudo-move of each piece-list entry
+  uint8_t l0[FPC_MAX_PL];              // own piece list before the GetGameResult reordering
+  uint8_t l1[FPC_MAX_PL];
+  int M, nlegal, first_legal, result, errbits;
+  float scal_f;                        // wave-uniform scalar broadcast slot
+};
+
+__device__ __forceinline__ bool present(uint8_t p) { return (p & 0x80) != 0; }
+__device__ __forceinline__ int colour_of(uint8_t p) { return (p >> 5) & 3; }
+__device__ __forceinline__ int type_of(uint8_t p) { return (p >> 2) & 7; }
+__device__ __forceinline__ int team_of_colour(int c) { return c & 1; }   // RED/YELLOW 0, BLUE/GREEN 1 (engine/board.h:64-67)
+__device__ __forceinline__ int team_of(uint8_t p) { return (p >> 5) & 1; }
+
+// engine/board.h:647-654
+__device__ __forceinline__ bool legal_loc(const DevCfg &c, int row, int col) {
+  const int mx = c.R - 1;
+  if (row < 0 || row > mx || col < 0 || col > mx) return false;
+  const bool cc = col < c.INV || col > mx - c.INV;
+  if (cc && (row < c.INV || row > mx - c.INV)) return false;
+  return true;
+}
+__host__ __device__ __forceinline__ bool in_array(const DevCfg &c, int row, int col) {
+  return row >= 0 && row < c.R && col >= 0 && col < c.R;
+}
+
+// move.cpp:13-20, :84-104: (from,to) -> action plane
+__host__ __device__ __forceinline__ int move_plane(const DevCfg &c, int from, int to) {
+  const int dy = to / c.R - from / c.R, dx = to % c.R - from % c.R;
+  const int ay = dy < 0 ? -dy : dy, ax = dx < 0 ? -dx : dx;
+  if (dx == 0 || dy == 0 || ax == ay) {
+    const int sx = (dx > 0) - (dx < 0), sy = (dy > 0) - (dy < 0);
+    // queen_move_offsets (dx,dy): {0,-1},{-1,-1},{-1,0},{-1,1},{0,1},{1,1},{1,0},{1,-1}
+    const int key = (sx + 1) * 3 + (sy + 1);
+    int dir;
+    switch (key) {
+      case 0: dir = 1; break; case 1: dir = 2; break; case 2: dir = 3; break;
+      case 3: dir = 0; break; case 5: dir = 4; break;
+      case 6: dir = 7; break; case 7: dir = 6; break; default: dir = 5; break;
+    }
+    const int dist = ax > ay ? ax : ay;
+    return dir * (c.R - 1) + dist - 1;
+  }
+  // knight_move_offsets (dx,dy): {-2,-1},{-2,1},{-1,-2},{-1,2},{1,-2},{1,2},{2,-1},{2,1}
+  const int k = (dx == -2 ? 0 : dx == -1 ? 2 : dx == 1 ? 4 : 6) + (dy > 0 ? 1 : 0);
+  return 8 * (c.R - 1) + k;
+}
+
+// Move(flat): move.cpp:39-61.  returns `to` (FPC_NO_SQ when off the array / unaddressable plane)
+__host__ __device__ __forceinline__ int flat_to(const DevCfg &c, int flat, int *from_out) {
+  const int plane = flat / c.RR, from = flat % c.RR;
+  *from_out = from;
+  const int nq = c.R - 1;
+  int dx, dy;
+  if (plane < 8 * nq) {
+    const int dir = plane / nq, dist = plane % nq + 1;
+    const int qdx[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+    const int qdy[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
+    dx = qdx[dir] * dist; dy = qdy[dir] * dist;
+  } else {
+    const int k = plane - 8 * nq;
+    if (k >= 8) return FPC_NO_SQ;
+    const int ndx[8] = {-2, -2, -1, -1, 1, 1, 2, 2};
+    const int ndy[8] = {-1, 1, -2, 2, -2, 2, -1, 1};
+    dx = ndx[k]; dy = ndy[k];
+  }
+  const int row = from / c.R + dy, col = from % c.R + dx;
+  if (!in_array(c, row, col)) return FPC_NO_SQ;
+  return row * c.R + col;
+}
+
+// torch.rot90(x, k, (-2,-1)) index map: out[i][j] = in[src]   (board.cpp:252-255)
+__device__ __forceinline__ int rot90_src(int R, int k, int i, int j) {
+  k &= 3;
+  return k == 0 ? i * R + j : k == 1 ? j * R + (R - 1 - i) : k == 2 ? (R - 1 - i) * R + (R - 1 - j) : (R - 1 - j) * R + i;
+}
+
+// ---- wave helpers -------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ void lds_load_board(WaveLds *s, const fpc_board *g) {
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(g);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(&s->b);
+  const int l = lane_id();
+  dst[l] = src[l];
+  if (l < 8) dst[64 + l] = src[64 + l];
+  __syncthreads();
+}
+__device__ __forceinline__ void lds_store_board(const WaveLds *s, fpc_board *g) {
+  __syncthreads();
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(&s->b);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(g);
+  const int l = lane_id();
+  dst[l] = src[l];
+  if (l < 8) dst[64 + l] = src[64 + l];
+}
+
+// piece-list primitive used by every reordering: erase the entry for `sq`, append it at the end
+// (== RemovePiece + SetPiece, engine/board.cpp:977-1014, as executed by a make/undo pair)
+__device__ __forceinline__ void list_move_to_end(uint8_t *list, int len, int sq) {
+  int i = 0;
+  while (i < len && list[i] != sq) ++i;
+  if (i >= len) return;
+  for (; i + 1 < len; ++i) list[i] = list[i + 1];
+  list[len - 1] = (uint8_t)sq;
+}
+
+// MakeMove for a tree/self-play move, which carries only (from,to): capture whatever stands on
+// `to`, no promotion, no rook hop, no rights update (engine/board.cpp:1028-1096 with a
+// Move(flat)/Move(plane,from) argument).  Executed by lane 0.  false: "piece missing".
+__device__ __forceinline__ bool make_move_lane0(fpc_board *b, int from, int to) {
+  if (to == FPC_NO_SQ) return false;
+  const uint8_t piece = b->sq[from];
+  const uint8_t cap = b->sq[to];
+  if (present(cap)) {  // RemovePiece(to)
+    const int cc = colour_of(cap);
+    uint8_t *l = b->pl[cc];
+    int n = b->plen[cc], i = 0;
+    while (i < n && l[i] != to) ++i;
+    if (i < n) { for (; i + 1 < n; ++i) l[i] = l[i + 1]; b->plen[cc] = (uint8_t)(n - 1); }
+    b->sq[to] = 0;
+    if (type_of(cap) == KING) b->king[cc] = FPC_NO_SQ;
+  }
+  if (!present(piece)) return false;
+  const int pc = colour_of(piece);
+  {  // RemovePiece(from) + SetPiece(to, piece)
+    uint8_t *l = b->pl[pc];
+    int n = b->plen[pc], i = 0;
+    while (i < n && l[i] != from) ++i;
+    if (i < n) { for (; i + 1 < n; ++i) l[i] = l[i + 1]; n--; }
+    if (n < FPC_MAX_PL) l[n++] = (uint8_t)to;
+    b->plen[pc] = (uint8_t)n;
+    b->sq[from] = 0;
+    b->sq[to] = piece;
+    if (type_of(piece) == KING) b->king[pc] = (uint8_t)to;
+  }
+  b->turn = (uint8_t)((b->turn + 1) & 3);  // GetNextPlayer, engine/board.cpp:1299-1313
+  return true;
+}
+
+// IsAttackedByTeam(team, ksq) on the position obtained from `b` by moving the piece on `from` to
+// `to` (virtual make; from==to==FPC_NO_SQ -> the position itself).  engine/board.cpp:606-787.
+__device__ inline bool attacked_virtual(const fpc_board *b, const DevCfg &c, int from, int to, uint8_t mover,
+                                        int ksq, int team) {
+  const int R = c.R;
+  const int kr = ksq / R, kc = ksq % R;
+#define FPC_VSQ(q) ((q) == from ? (uint8_t)0 : ((q) == to ? mover : b->sq[(q)]))
+  // rooks & queens: rays end at the ARRAY edge, not at the cut corners (:632)
+  for (int d = 0; d < 4; ++d) {
+    const int ri = d == 0 ? -1 : d == 1 ? 1 : 0, ci = d == 2 ? -1 : d == 3 ? 1 : 0;
+    int r = kr + ri, cc = kc + ci;
+    while (in_array(c, r, cc)) {
+      const int q = r * R + cc;
+      const uint8_t p = FPC_VSQ(q);
+      if (present(p)) {
+        if (team_of(p) == team && (type_of(p) == ROOK || type_of(p) == QUEEN)) return true;
+        break;
+      }
+      r += ri; cc += ci;
+    }
+  }
+  // bishops & queens: bounded by IsLegalLocation (:658)
+  for (int d = 0; d < 4; ++d) {
+    const int ri = (d & 2) ? 1 : -1, ci = (d & 1) ? 1 : -1;
+    int r = kr + ri, cc = kc + ci;
+    while (legal_loc(c, r, cc)) {
+      const int q = r * R + cc;
+      const uint8_t p = FPC_VSQ(q);
+      if (present(p)) {
+        if (team_of(p) == team && (type_of(p) == BISHOP || type_of(p) == QUEEN)) return true;
+        break;
+      }
+      r += ri; cc += ci;
+    }
+  }
+  // knights: all 8 offsets regardless of board size (:676-694)
+  for (int k = 0; k < 8; ++k) {
+    const int dr = (k & 4) ? ((k & 2) ? 1 : -1) : ((k & 2) ? 2 : -2);
+    const int dc = (k & 4) ? ((k & 1) ? 2 : -2) : ((k & 1) ? 1 : -1);
+    const int r = kr + dr, cc = kc + dc;
+    if (legal_loc(c, r, cc)) {
+      const int q = r * R + cc;
+      const uint8_t p = FPC_VSQ(q);
+      if (present(p) && team_of(p) == team && type_of(p) == KNIGHT) return true;
+    }
+  }
+  // pawns (:697-750): array bounds only
+  for (int k = 0; k < 4; ++k) {
+    const int pr = k >> 1, pc = k & 1;
+    const int r = pr ? kr + 1 : kr - 1, cc = pc ? kc + 1 : kc - 1;
+    if (in_array(c, r, cc)) {
+      const int q = r * R + cc;
+      const uint8_t p = FPC_VSQ(q);
+      if (present(p) && team_of(p) == team && type_of(p) == PAWN) {
+        const int col = colour_of(p);
+        const bool att = col == 0 ? pr != 0 : col == 1 ? pc == 0 : col == 2 ? pr == 0 : pc != 0;
+        if (att) return true;
+      }
+    }
+  }
+  // kings (:753-772)
+  for (int k = 0; k < 9; ++k) {
+    if (k == 4) continue;
+    const int r = kr + k / 3 - 1, cc = kc + k % 3 - 1;
+    if (legal_loc(c, r, cc)) {
+      const int q = r * R + cc;
+      const uint8_t p = FPC_VSQ(q);
+      if (present(p) && team_of(p) == team && type_of(p) == KING) return true;
+    }
+  }
+#undef FPC_VSQ
+  return false;
+}
+
+// Enumerates, in the reference's generation order, the targets of generator slot `d` (0..7) of the
+// piece standing on `from`:  pawn {fwd1, fwd2, capture-, capture+} (engine/board.cpp:97-177),
+// knight (:179-207, loop bound invalid_area = quirk Q8), bishop (:240-254), rook (:256-302),
+// queen = bishop then rook (:304-311), king 8 steps (:313-341).  emit(to, capture, promo).
+template <class F>
+__device__ inline void walk_slot(const fpc_board *b, const DevCfg &c, int from, int d, F &&emit) {
+  const uint8_t piece = b->sq[from];
+  const int type = type_of(piece), colour = colour_of(piece), team = team_of(piece);
+  const int R = c.R, fr = from / R, fc = from % R;
+  int ir = 0, ic = 0;
+  bool ray = false;
+  switch (type) {
+    case PAWN: {
+      if (d >= 4) return;
+      int dr = 0, dc = 0;
+      bool not_moved;
+      switch (colour) {
+        case 0: dr = -1; not_moved = fr == R - 2; break;
+        case 1: dc = 1; not_moved = fc == 1; break;
+        case 2: dr = 1; not_moved = fr == 1; break;
+        default: dc = -1; not_moved = fc == R - 2; break;
+      }
+      int tr, tc;
+      uint8_t cap = 0;
+      if (d < 2) {
+        tr = fr + dr; tc = fc + dc;
+        if (!legal_loc(c, tr, tc) || present(b->sq[tr * R + tc])) return;
+        if (d == 1) {
+          if (!not_moved) return;
+          tr = fr + 2 * dr; tc = fc + 2 * dc;
+          if (!in_array(c, tr, tc) || present(b->sq[tr * R + tc])) return;  // no legality check on the 2nd square (Q15)
+        }
+      } else {
+        tr = fr + dr; tc = fc + dc;
+        const int s = d == 2 ? -1 : 1;
+        if (team == 0) tc += s; else tr += s;
+        if (!legal_loc(c, tr, tc)) return;
+        cap = b->sq[tr * R + tc];
+        if (!present(cap) || team_of(cap) == team) return;
+      }
+      bool promo;  // engine/board.cpp:58-76
+      switch (colour) {
+        case 0: promo = tr == R / 4; break;
+        case 1: promo = tc == 3 * R / 4; break;
+        case 2: promo = tr == 3 * R / 4; break;
+        default: promo = tc == R / 4; break;
+      }
+      emit(tr * R + tc, cap, promo);
+      return;
+    }
+    case KNIGHT: {
+      const int per = 2 * (c.INV - 1);
+      if (d >= 2 * per) return;
+      const int prs = d / per, rem = d % per, adr = 1 + rem / 2, pcs = rem & 1;
+      const int dr = prs ? adr : -adr, adc = adr == 1 ? 2 : 1, dc = pcs ? adc : -adc;
+      const int tr = fr + dr, tc = fc + dc;
+      if (!legal_loc(c, tr, tc)) return;
+      const uint8_t cap = b->sq[tr * R + tc];
+      if (present(cap) && team_of(cap) == team) return;
+      emit(tr * R + tc, cap, false);
+      return;
+    }
+    case BISHOP:
+      if (d >= 4) return;
+      ir = (d & 2) ? 1 : -1; ic = (d & 1) ? 1 : -1; ray = true;
+      break;
+    case ROOK:
+    case QUEEN: {
+      // rook generator order (:291-301): (0,-1), (-1,0), (0,+1), (+1,0)
+      int rd = d;
+      if (type == QUEEN) {
+        if (d < 4) { ir = (d & 2) ? 1 : -1; ic = (d & 1) ? 1 : -1; ray = true; break; }
+        rd = d - 4;
+      }
+      if (rd >= 4) return;
+      const int incr = (rd & 2) ? 1 : -1;
+      if (rd & 1) { ir = incr; ic = 0; } else { ir = 0; ic = incr; }
+      ray = true;
+      break;
+    }
+    case KING: {
+      const int k = d < 4 ? d : d + 1;
+      const int tr = fr + k / 3 - 1, tc = fc + k % 3 - 1;
+      if (!legal_loc(c, tr, tc)) return;
+      const uint8_t cap = b->sq[tr * R + tc];
+      if (present(cap) && team_of(cap) == team) return;
+      emit(tr * R + tc, cap, false);
+      return;
+    }
+    default:
+      return;
+  }
+  if (ray) {  // AddMovesFromIncrMovement2, engine/board.cpp:209-238
+    int tr = fr + ir, tc = fc + ic;
+    while (legal_loc(c, tr, tc)) {
+      const uint8_t cap = b->sq[tr * R + tc];
+      if (!present(cap)) {
+        emit(tr * R + tc, (uint8_t)0, false);
+      } else {
+        if (team_of(cap) != team) emit(tr * R + tc, cap, false);
+        break;
+      }
+      tr += ir; tc += ic;
+    }
+  }
+}
+
+// Wave-cooperative movegen + legality + (optionally) GetGameResult / GetLegalMoves side effects.
+//   do_result: run Board::GetGameResult(player) (engine/board.cpp:891-939) -> s->result, and apply
+//              the piece-list reordering of its make/undo loop (stops at the first legal move).
+//   do_legal : run fpchess::Board::GetLegalMoves (board.cpp:94-118) -> s->lflat/lidx/lsorted,
+//              s->nlegal, and apply the reordering of its full make/undo loop.  Skipped when
+//              do_result found a terminal position (ChooseLeaf returns before the mask is built).
+// `player` < 0 -> side to move.  All lanes of the wave must call this (uniform control flow).
+__device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_result, bool do_legal, int player) {
+  const int lane = lane_id();
+  fpc_board *b = &s->b;
+  const int turn = b->turn;
+  if (player < 0) player = turn;
+  const int nown = b->plen[turn];
+  const bool gen = b->king[turn] != FPC_NO_SQ;   // GetPseudoLegalMoves2 returns 0 without own king (:852-856)
+  const bool player_has_king = b->king[player] != FPC_NO_SQ;
+
+  // ---- pass 1: count the moves of this lane's two generator slots (piece p, directions d0,d0+1)
+  const int p = lane >> 2, d0 = (lane & 3) * 2;
+  int cnt0 = 0, cnt1 = 0;
+  int from = FPC_NO_SQ;
+  if (gen && p < nown) {
+    from = b->pl[turn][p];
+    walk_slot(b, c, from, d0, [&](int, uint8_t, bool) { ++cnt0; });
+    walk_slot(b, c, from, d0 + 1, [&](int, uint8_t, bool) { ++cnt1; });
+  }
+  // exclusive wave scan of (cnt0+cnt1) in lane order == reference generation order
+  int incl = cnt0 + cnt1;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  const int total = __shfl(incl, 63);
+  int base = incl - (cnt0 + cnt1);
+  if ((lane & 3) == 0 && p <= FPC_MAX_PL - 1) s->poff[p] = (uint16_t)(base < FPC_MAX_MOVES ? base : FPC_MAX_MOVES);
+  if (lane == 0) {
+    s->poff[FPC_MAX_PL] = (uint16_t)(total < FPC_MAX_MOVES ? total : FPC_MAX_MOVES);
+    s->errbits = total > FPC_MAX_MOVES ? ERR_CAP_MOVES : 0;
+    if (nown > FPC_MAX_PL) s->errbits |= ERR_CAP_MOVES;
+  }
+  const int M = total < FPC_MAX_MOVES ? total : FPC_MAX_MOVES;
+  // ---- pass 2: write them
+  if (from != FPC_NO_SQ) {
+    int w = base;
+    auto put = [&](int to, uint8_t cap, bool promo) {
+      if (w < FPC_MAX_MOVES) {
+        s->mfrom[w] = (uint8_t)from; s->mto[w] = (uint8_t)to; s->mcap[w] = cap; s->mflag[w] = promo ? 2 : 0;
+      }
+      ++w;
+    };
+    walk_slot(b, c, from, d0, put);
+    walk_slot(b, c, from, d0 + 1, put);
+  }
+  __syncthreads();
+
+  // ---- legality: lane i tests move i on the virtual post-move board (IsKingSafeAfterMove, board.cpp:59-68)
+  const int enemy = team_of_colour(player) ^ 1;
+  int nlegal = 0, first = -1;
+  for (int base_i = 0; base_i < M; base_i += 64) {
+    const int i = base_i + lane;
+    bool legal = false;
+    if (i < M) {
+      const int f = s->mfrom[i], t = s->mto[i];
+      const uint8_t mover = b->sq[f];
+      int ksq = b->king[player];
+      if (type_of(mover) == KING && colour_of(mover) == player) ksq = t;
+      else if (ksq == t) ksq = FPC_NO_SQ;               // the player's king itself was captured
+      legal = ksq == FPC_NO_SQ ? true : !attacked_virtual(b, c, f, t, mover, ksq, enemy);
+      if (legal) s->mflag[i] |= 1;
+    }
+    const unsigned long long bal = __ballot(legal);
+    if (legal) {
+      const int k = nlegal + __popcll(bal & ((1ull << lane) - 1ull));
+      s->lidx[k] = (uint8_t)i;
+      s->lflat[k] = (uint16_t)(move_plane(c, s->mfrom[i], s->mto[i]) * c.RR + s->mfrom[i]);
+    }
+    if (first < 0 && bal) first = base_i + (int)__ffsll((long long)bal) - 1;
+    nlegal += __popcll(bal);
+  }
+  __syncthreads();
+
+  // ---- GetGameResult (engine/board.cpp:891-939)
+  int result = FPC_IN_PROGRESS;
+  if (do_result) {
+    if (!player_has_king) {
+      result = team_of_colour(player) == 0 ? FPC_WIN_BG : FPC_WIN_RY;
+    } else if (nlegal > 0) {
+      const uint8_t cap = s->mcap[first];                // only the FIRST legal move is inspected (Q13)
+      if (present(cap) && type_of(cap) == KING) result = team_of(cap) == 0 ? FPC_WIN_BG : FPC_WIN_RY;
+    } else {
+      const bool chk = attacked_virtual(b, c, FPC_NO_SQ, FPC_NO_SQ, 0, b->king[player], enemy);
+      result = !chk ? FPC_STALEMATE : (team_of_colour(player) == 0 ? FPC_WIN_BG : FPC_WIN_RY);
+    }
+  }
+  const bool run_legal = do_legal && result == FPC_IN_PROGRESS;
+
+  // ---- piece-list reorderings caused by the reference's make/undo loops (lane 0, closed form:
+  //      every make/undo pair moves the mover's entry, then the captured piece's entry, to the end
+  //      of their lists; engine/board.cpp:1028-1160)
+  if (lane == 0) {
+    if (do_result && player_has_king) {
+      for (int i = 0; i < nown && i < FPC_MAX_PL; ++i) s->l0[i] = b->pl[turn][i];
+      const int upto = nlegal > 0 ? first : M - 1;       // loop returns at the first legal move
+      for (int i = 0; i <= upto; ++i) {
+        list_move_to_end(b->pl[turn], nown, s->mfrom[i]);
+        const uint8_t cap = s->mcap[i];
+        if (present(cap)) list_move_to_end(b->pl[colour_of(cap)], b->plen[colour_of(cap)], s->mto[i]);
+      }
+    }
+    if (run_legal) {
+      // GetLegalMoves regenerates the pseudo-legal moves from the CURRENT list order: same moves,
+      // grouped per piece in that order.  poff[] is indexed by the position in the list the moves
+      // were generated from (l0 if do_result ran, else the current list).
+      const bool remap = do_result && player_has_king;
+      for (int i = 0; i < nown && i < FPC_MAX_PL; ++i) s->l1[i] = b->pl[turn][i];
+      for (int k = 0; k < nown && k < FPC_MAX_PL; ++k) {
+        const int sq = s->l1[k];
+        int p0 = k;
+        if (remap) { p0 = 0; while (p0 < nown && s->l0[p0] != sq) ++p0; }
+        const int a = s->poff[p0], e = s->poff[p0 + 1];
+        if (e > a) list_move_to_end(b->pl[turn], nown, sq);
+        for (int i = a; i < e; ++i) {
+          const uint8_t cap = s->mcap[i];
+          if (present(cap)) list_move_to_end(b->pl[colour_of(cap)], b->plen[colour_of(cap)], s->mto[i]);
+        }
+      }
+    }
+    s->M = M; s->nlegal = run_legal ? nlegal : 0; s->first_legal = first; s->result = result;
+  }
+  __syncthreads();
+
+  // ---- ascending flat order of the legal set (children are created in torch.nonzero order,
+  //      mcts.py:84-87): rank sort, promotions are already collapsed to one entry
+  if (run_legal) {
+    for (int j = lane; j < nlegal; j += 64) {
+      const uint16_t v = s->lflat[j];
+      int rank = 0;
+      for (int k = 0; k < nlegal; ++k) rank += s->lflat[k] < v;
+      s->lsorted[rank] = v;
+    }
+  }
+  __syncthreads();
+}
+
+// ================================================================================================
+// k_board_ops: the batched Board API (one wave per position)
+// ================================================================================================
+enum { OP_LEGAL = 1, OP_RESULT = 2, OP_TAKE = 4 };
+
+__global__ void __launch_bounds__(64) k_board_ops(DevCfg c, fpc_board *boards, int n, int ops, const int *player,
+                                                  const int *flat, fpc_move *moves, int *counts, int *results,
+                                                  int *err) {
+  __shared__ WaveLds s;
+  const int g = blockIdx.x;
+  if (g >= n) return;
+  const int lane = lane_id();
+  lds_load_board(&s, &boards[g]);
+  int e = 0;
+  if (ops & OP_TAKE) {
+    if (lane == 0) {
+      int from;
+      const int to = flat_to(c, flat[g], &from);
+      s.errbits = make_move_lane0(&s.b, from, to) ? 0 : ERR_MOVE;
+    }
+    __syncthreads();
+    e |= s.errbits;
+  }
+  if (ops & (OP_LEGAL | OP_RESULT)) {
+    wave_position_ops(&s, c, (ops & OP_RESULT) != 0, (ops & OP_LEGAL) != 0, player ? player[g] : -1);
+    e |= s.errbits;
+    if (ops & OP_RESULT) { if (lane == 0) results[g] = s.result; }
+    if (ops & OP_LEGAL) {
+      const int nl = s.nlegal;
+      if (lane == 0) counts[g] = nl;
+      for (int k = lane; k < nl; k += 64) {
+        const int i = s.lidx[k];
+        fpc_move m;
+        m.from = s.mfrom[i]; m.to = s.mto[i]; m.capture = s.mcap[i]; m.promo = (s.mflag[i] >> 1) & 1;
+        m.flat = s.lflat[k]; m.pad = 0;
+        moves[(size_t)g * FPC_MAX_MOVES + k] = m;
+      }
+    }
+  }
+  lds_store_board(&s, &boards[g]);
+  if (lane == 0) err[g] = e;
+}
+
+// ================================================================================================
+// k_encode: Board::GetEncodedStates (board.cpp:305-356).  plane = 6*((colour-turn)&3) + type - 1,
+// -1 wrapping to 23 (Q7); whole batch rotated by the turn of the FIRST leaf (Q6).
+// mode 0: f32 NCHW [G,24,R,R]   (reference layout; external evaluators, parity tests)
+// mode 1: 16-bit NHWC on the zero-bordered (R+2)x(R+2) grid, 32 channels (24 + 8 zero) -- the
+//         input image of the internal MFMA conv stack.  one16 = bit pattern of 1.0 in the NN dtype.
+// ================================================================================================
+__device__ __forceinline__ int first_leaf_turn(const int *leaf_node, const int *leaf_turn, int G) {
+  const int lane = lane_id();
+  int found = -1;
+  for (int base = 0; base < G && found < 0; base += 64) {
+    const int g = base + lane;
+    const bool has = g < G && leaf_node[g] >= 0;
+    const unsigned long long bal = __ballot(has);
+    if (bal) found = base + (int)__ffsll((long long)bal) - 1;
+  }
+  return found < 0 ? 0 : leaf_turn[found];
+}
+
+__global__ void __launch_bounds__(64) k_encode(DevCfg c, const fpc_board *boards, int board_stride,
+                                               const int *slot_of, const int *leaf_turn, int G, int mode,
+                                               float *out_f32, uint16_t *out_nhwc, uint16_t one16,
+                                               int fixed_rot /* <0: rotation from first live leaf */) {
+  const int g = blockIdx.x;
+  if (g >= G) return;
+  const int lane = lane_id();
+  const int slot = slot_of ? slot_of[g] : 0;   // for the search: leaf board slot (or -1 dead)
+  const int k = fixed_rot >= 0 ? fixed_rot : first_leaf_turn(slot_of, leaf_turn, G);
+  const int R = c.R, RR = c.RR;
+  const bool live = slot >= 0;
+  const fpc_board *b = live ? &boards[(size_t)g * board_stride + slot] : nullptr;
+  const int turn = live ? b->turn : 0;
+  if (mode == 0) {
+    float *o = out_f32 + (size_t)g * 24 * RR;
+    for (int pos = lane; pos < RR; pos += 64) {
+      int plane = -1;
+      if (live) {
+        const uint8_t p = b->sq[rot90_src(R, k, pos / R, pos % R)];
+        if (present(p)) { plane = 6 * ((colour_of(p) - turn) & 3) + type_of(p) - 1; if (plane < 0) plane += 24; }
+      }
+      for (int pl = 0; pl < 24; ++pl) o[(size_t)pl * RR + pos] = pl == plane ? 1.0f : 0.0f;
+    }
+  } else {
+    const int P = R + 2;
+    uint16_t *o = out_nhwc + (size_t)g * P * P * 32;
+    for (int pos = lane; pos < RR; pos += 64) {
+      int plane = -1;
+      const int i = pos / R, j = pos % R;
+      if (live) {
+        const uint8_t p = b->sq[rot90_src(R, k, i, j)];
+        if (present(p)) { plane = 6 * ((colour_of(p) - turn) & 3) + type_of(p) - 1; if (plane < 0) plane += 24; }
+      }
+      uint32_t *row = reinterpret_cast<uint32_t *>(o + ((size_t)(i + 1) * P + (j + 1)) * 32);
+      for (int w = 0; w < 16; ++w) {
+        uint32_t v = 0;
+        if (plane == 2 * w) v = one16; else if (plane == 2 * w + 1) v = (uint32_t)one16 << 16;
+        row[w] = v;
+      }
+    }
+  }
+}
+
+// legal-move mask (four_player_chess_board.py:36-56): dense 0/1 [n,A_ch,R,R] f32 in absolute coords
+__global__ void __launch_bounds__(64) k_mask_from_moves(DevCfg c, const fpc_move *moves, const int *counts, int n,
+                                                         float *out) {
+  const int g = blockIdx.x;
+  if (g >= n) return;
+  const int lane = lane_id();
+  float *o = out + (size_t)g * c.A;
+  for (int i = lane; i < c.A; i += 64) o[i] = 0.f;
+  __syncthreads();
+  for (int k = lane; k < counts[g]; k += 64) o[moves[(size_t)g * FPC_MAX_MOVES + k].flat] = 1.0f;
+}
+
+// ================================================================================================
+// k_search_init: fresh root per game (mcts.py:29-32: Node(C, game, visit_count=1))
+// ================================================================================================
+__global__ void __launch_bounds__(64) k_search_init(Tree t, int G, const fpc_board *roots) {
+  const int g = blockIdx.x;
+  if (g >= G) return;
+  const int lane = lane_id();
+  {  // root state -> board-pool slot 0 of this game
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&roots[g]);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&t.boards[(size_t)g * t.board_cap]);
+    dst[lane] = src[lane];
+    if (lane < 8) dst[64 + lane] = src[64 + lane];
+  }
+  if (lane != 0) return;
+  const size_t nb = (size_t)g * t.node_cap;
+  t.N[nb] = 1; t.W[nb] = 0.0; t.P[nb] = 0.f; t.mv[nb] = 0xffff; t.parent[nb] = -1; t.child0[nb] = -1; t.nch[nb] = 0;
+  t.bslot[nb] = 0;
+  t.nnodes[g] = 1; t.nboards[g] = 1; t.alive[g] = 1; t.sims_done[g] = 0; t.err[g] = 0;
+  t.leaf_node[g] = -1; t.leaf_turn[g] = 0; t.nlegal[g] = 0;
+}
+
+// root read-back (alphazero.py:104-110 reads GetChildren / GetFlatIndex / GetVisitCount)
+__global__ void __launch_bounds__(64) k_root_children(Tree t, int G, int maxc, int *flat, int *visits, float *prior,
+                                                      double *wsum, int *meta, fpc_board *roots_out) {
+  const int g = blockIdx.x;
+  if (g >= G) return;
+  const int lane = lane_id();
+  const size_t nb = (size_t)g * t.node_cap;
+  const int c0 = t.child0[nb], nc = c0 < 0 ? 0 : (int)t.nch[nb];
+  for (int k = lane; k < nc && k < maxc; k += 64) {
+    const size_t o = (size_t)g * maxc + k;
+    flat[o] = t.mv[nb + c0 + k]; visits[o] = t.N[nb + c0 + k]; prior[o] = t.P[nb + c0 + k]; wsum[o] = t.W[nb + c0 + k];
+  }
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&t.boards[(size_t)g * t.board_cap]);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&roots_out[g]);
+    dst[lane] = src[lane];
+    if (lane < 8) dst[64 + lane] = src[64 + lane];
+  }
+  if (lane == 0) { meta[g * 3 + 0] = t.N[nb]; meta[g * 3 + 1] = nc; meta[g * 3 + 2] = t.sims_done[g]; }
+}
+
+// ================================================================================================
+// k_select: get_expandable_leaves / Node::ChooseLeaf (mcts.py:18-26, node.cpp:19-78)
+// ================================================================================================
+// Node::Backpropagate (node.cpp:133-142): value_sum += (double)v ; visit_count += 1 ; v = -v (f32)
+__device__ __forceinline__ void backprop_lane0(const Tree &t, size_t nb, int n, float v) {
+  while (n >= 0) {
+    t.W[nb + n] += (double)v;
+    t.N[nb + n] += 1;
+    v = -v;
+    n = t.parent[nb + n];
+  }
+}
+
+__global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double Cpuct, const double *logtab) {
+  __shared__ WaveLds s;
+  const int g = blockIdx.x;
+  if (g >= G) return;
+  const int lane = lane_id();
+  if (!t.alive[g]) {                        // root already removed from the search (Q5)
+    if (lane == 0) t.leaf_node[g] = -1;
+    return;
+  }
+  const size_t nb = (size_t)g * t.node_cap;
+  // ---- descent: SelectChild (node.cpp:49-78)
+  //   ucb_i = W_i/N_i + C * sqrt( log(sqrt(N_parent)) / (1 + N_i) ) * P_i      (fp64, no contraction)
+  //   strict '>' from -inf => lowest index wins ties, NaN never wins
+  int n = 0;
+  bool fail = false;
+  for (;;) {
+    const int c0 = t.child0[nb + n];
+    if (c0 < 0) break;
+    const int nc = t.nch[nb + n];
+    const double L = logtab[t.N[nb + n]];
+    double best = 0.0;
+    int besti = -1;
+    for (int base = 0; base < nc; base += 64) {
+      const int i = base + lane;
+      double u = 0.0;
+      bool valid = false;
+      if (i < nc) {
+        const int Nc = t.N[nb + c0 + i];
+        const double Wc = t.W[nb + c0 + i];
+        const double Pc = (double)t.P[nb + c0 + i];
+        const double q = Nc > 0 ? Wc / (double)Nc : 0.0;
+        const double e = Cpuct * sqrt(L / (double)(1 + Nc));
+        u = q + e * Pc;
+        valid = u > -__builtin_inf();
+      }
+      int idx = valid ? i : 0x7fffffff;
+      if (!valid) u = -__builtin_inf();
+      for (int off = 32; off >= 1; off >>= 1) {
+        const double u2 = __shfl_xor(u, off);
+        const int i2 = __shfl_xor(idx, off);
+        if (u2 > u || (u2 == u && i2 < idx)) { u = u2; idx = i2; }
+      }
+      if (idx != 0x7fffffff && (besti < 0 || u > best)) { best = u; besti = idx; }
+    }
+    if (besti < 0) { fail = true; break; }
+    n = c0 + besti;
+  }
+  if (fail) {                                // node.cpp:72-75 throws
+    if (lane == 0) { t.err[g] |= ERR_SELECT; t.alive[g] = 0; t.leaf_node[g] = -1; }
+    return;
+  }
+  // ---- leaf state: the reference copies + MakeMoves a Board for every child at expansion time
+  //      (node.cpp:90-91); here it is materialised the first time the node is reached.
+  int slot = t.bslot[nb + n];
+  const fpc_board *pool = t.boards + (size_t)g * t.board_cap;
+  if (slot < 0) {
+    const int par = t.parent[nb + n];
+    lds_load_board(&s, &pool[t.bslot[nb + par]]);
+    if (lane == 0) {
+      int from;
+      const int to = flat_to(c, t.mv[nb + n], &from);
+      int e = make_move_lane0(&s.b, from, to) ? 0 : ERR_MOVE;
+      int ns = t.nboards[g];
+      if (ns >= t.board_cap) { e |= ERR_CAP_BOARDS; ns = t.board_cap - 1; } else t.nboards[g] = ns + 1;
+      t.bslot[nb + n] = ns;
+      s.first_legal = ns;                    // broadcast through LDS
+      if (e) t.err[g] |= e;
+    }
+    __syncthreads();
+    slot = s.first_legal;
+    __syncthreads();
+  } else {
+    lds_load_board(&s, &pool[slot]);
+  }
+  // ---- GetGameResult (node.cpp:28-29) then, if in progress, GetLegalMoves
+  //      (four_player_chess_board.py:38) on the same state, with their list reorderings
+  wave_position_ops(&s, c, true, true, -1);
+  lds_store_board(&s, &t.boards[(size_t)g * t.board_cap + slot]);
+  const int res = s.result;
+  if (lane == 0 && s.errbits) t.err[g] |= s.errbits;
+  if (res != FPC_IN_PROGRESS) {              // node.cpp:31-42: back up 0 / -1, drop the root (Q5)
+    if (lane == 0) {
+      backprop_lane0(t, nb, n, res == FPC_STALEMATE ? 0.0f : -1.0f);
+      t.sims_done[g] += 1;
+      t.alive[g] = 0;
+      t.leaf_node[g] = -1;
+    }
+    return;
+  }
+  const int nl = s.nlegal;
+  uint16_t *lg = t.legal + (size_t)g * FPC_MAX_MOVES;
+  for (int k = lane; k < nl; k += 64) lg[k] = s.lsorted[k];
+  if (lane == 0) { t.leaf_node[g] = n; t.leaf_turn[g] = s.b.turn; t.nlegal[g] = nl; }
+}
+
+// leaf board slot per game for k_encode (-1 when the game has no leaf this step)
+__global__ void __launch_bounds__(64) k_leaf_slots(Tree t, int G, int *slot_out) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= G) return;
+  const int n = t.leaf_node[g];
+  slot_out[g] = n < 0 ? -1 : t.bslot[(size_t)g * t.node_cap + n];
+}
+
+// ================================================================================================
+// deterministic f32 exp shared (as a numeric SPEC, DESIGN.md "fpc_expf") with the test oracle:
+// k = rint(x*log2e); r = x - k*ln2 (two fma steps); degree-7 Horner in fma; scale by 2^k.
+// ================================================================================================
+__device__ __forceinline__ float fpc_expf(float x) {
+  if (x != x) return x;
+  if (x < -86.0f) return 0.0f;
+  if (x > 88.0f) return __builtin_inff();
+  const float k = __builtin_rintf(x * 0x1.715476p+0f);
+  float r = __builtin_fmaf(k, -0x1.62e4p-1f, x);
+  r = __builtin_fmaf(k, -0x1.7f7d1cp-20f, r);
+  float p = 0x1.a01a02p-13f;
+  p = __builtin_fmaf(p, r, 0x1.6c16c2p-10f);
+  p = __builtin_fmaf(p, r, 0x1.111112p-7f);
+  p = __builtin_fmaf(p, r, 0x1.555556p-5f);
+  p = __builtin_fmaf(p, r, 0x1.555556p-3f);
+  p = __builtin_fmaf(p, r, 0.5f);
+  p = __builtin_fmaf(p, r, 1.0f);
+  p = __builtin_fmaf(p, r, 1.0f);
+  const int ki = (int)k;
+  const uint32_t bits = (uint32_t)(ki + 127) << 23;
+  float sc;
+  __builtin_memcpy(&sc, &bits, 4);
+  return p * sc;
+}
+
+__device__ __forceinline__ float fdiv_rn(float a, float b) {
+#ifdef FPC_EMUL
+  return a / b;
+#else
+  return __fdiv_rn(a, b);
+#endif
+}
+
+// ================================================================================================
+// k_expand: mcts.py:67-89 for one leaf per wave.
+//   p = softmax(logits) over all A entries;  policy_abs[pl][r][c] = p[pl][rot90 by -turn0]  (Q6);
+//   prior_j = p_src(j) / sum_legal p  for the ascending legal list; exact zeros get no child;
+//   BackpropagateNodes(value) first (Q4), then children appended with N=1 (Q1), W=0.
+// Summation orders are part of the numeric spec: S = lane partials over float4 groups
+// (group q belongs to lane q%64, ascending) + xor butterfly; the legal mass is a sequential
+// ascending f32 sum.
+// ================================================================================================
+__global__ void __launch_bounds__(64) k_expand(DevCfg c, Tree t, int G, const float *logits, const float *value) {
+  __shared__ WaveLds s;
+  const int g = blockIdx.x;
+  if (g >= G) return;
+  const int lane = lane_id();
+  const int turn0 = first_leaf_turn(t.leaf_node, t.leaf_turn, G);
+  const int n = t.leaf_node[g];
+  if (n < 0) return;
+  const size_t nb = (size_t)g * t.node_cap;
+  const float *lg = logits + (size_t)g * c.A;
+  const int A = c.A, ngroups = A / 4;        // A = (8R+8)*R*R is a multiple of 4 for even R
+  // pass 1: max
+  float m = -__builtin_inff();
+  bool nan = false;
+  for (int q = lane; q < ngroups; q += 64) {
+    const float4 v = *reinterpret_cast<const float4 *>(lg + 4 * q);
+    nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+    m = v.x > m ? v.x : m; m = v.y > m ? v.y : m; m = v.z > m ? v.z : m; m = v.w > m ? v.w : m;
+  }
+  for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(m, off); m = o > m ? o : m; }
+  nan = __ballot(nan) != 0ull;
+  // pass 2: S
+  float part = 0.f;
+  for (int q = lane; q < ngroups; q += 64) {
+    const float4 v = *reinterpret_cast<const float4 *>(lg + 4 * q);
+    part = part + fpc_expf(v.x - m);
+    part = part + fpc_expf(v.y - m);
+    part = part + fpc_expf(v.z - m);
+    part = part + fpc_expf(v.w - m);
+  }
+  for (int off = 32; off >= 1; off >>= 1) part = part + __shfl_xor(part, off);
+  const float inv = fdiv_rn(1.0f, part);
+  // legal priors
+  const int nl = t.nlegal[g];
+  const uint16_t *legal = t.legal + (size_t)g * FPC_MAX_MOVES;
+  for (int j = lane; j < nl; j += 64) {
+    const int fl = legal[j];
+    const int plane = fl / c.RR, pos = fl % c.RR;
+    const int src = plane * c.RR + rot90_src(c.R, -turn0, pos / c.R, pos % c.R);
+    s.pri[j] = fpc_expf(lg[src] - m) * inv;
+    s.lsorted[j] = (uint16_t)fl;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    float T = 0.f;
+    for (int j = 0; j < nl; ++j) T = T + s.pri[j];
+    s.errbits = (nan || !(T > 0.f)) ? ERR_POLICY : 0;
+    s.scal_f = T;
+  }
+  __syncthreads();
+  if (s.errbits) {                          // the reference would expand all A indices and throw
+    if (lane == 0) { t.err[g] |= ERR_POLICY; t.alive[g] = 0; }
+    return;
+  }
+  const float T = s.scal_f;
+  // BackpropagateNodes (mcts.py:78) before ExpandNodes (mcts.py:79)
+  if (lane == 0) {
+    backprop_lane0(t, nb, n, value[g]);
+    t.sims_done[g] += 1;
+  }
+  // children: ascending flat order, entries with prior == 0 dropped (torch.nonzero, mcts.py:84)
+  const int base_node = t.nnodes[g];
+  int created = 0;
+  for (int b0 = 0; b0 < nl; b0 += 64) {
+    const int j = b0 + lane;
+    float pr = 0.f;
+    bool nz = false;
+    if (j < nl) { pr = fdiv_rn(s.pri[j], T); nz = pr != 0.f; }
+    const unsigned long long bal = __ballot(nz);
+    if (nz) {
+      const int k = base_node + created + __popcll(bal & ((1ull << lane) - 1ull));
+      if (k < t.node_cap) {
+        t.N[nb + k] = 1; t.W[nb + k] = 0.0; t.P[nb + k] = pr; t.mv[nb + k] = s.lsorted[j];
+        t.parent[nb + k] = n; t.child0[nb + k] = -1; t.nch[nb + k] = 0; t.bslot[nb + k] = -1;
+      }
+    }
+    created += __popcll(bal);
+  }
+  if (lane == 0) {
+    if (base_node + created > t.node_cap) { t.err[g] |= ERR_CAP_NODES; t.alive[g] = 0; }
+    else if (created > 0) {
+      t.child0[nb + n] = base_node; t.nch[nb + n] = (uint16_t)created; t.nnodes[g] = base_node + created;
+    }
+  }
+}
+
+}  // namespace fpc

@@ -1,0 +1,288 @@
+"""ctypes binding of the C-ABI in include/fpc_engine.h (libfpc_engine.so, built by hipcc for gfx950).
+
+There is no CPU implementation behind this module: if the HIP library is missing or no GPU is
+visible, loading / Engine() raises.  Everything above this file (alphazero_cpp.py, mcts.py,
+four_player_chess_board.py) is the Python mirror of the reference's binding surface.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libfpc_engine.so")
+
+MAX_SQ, MAX_PL, NO_SQ, MAX_MOVES = 196, 16, 255, 256
+
+
+class Board(C.Structure):
+    """fpc_board: the 288-byte POD position (include/fpc_engine.h)."""
+    _fields_ = [("sq", C.c_uint8 * MAX_SQ), ("pl", (C.c_uint8 * MAX_PL) * 4), ("plen", C.c_uint8 * 4),
+                ("king", C.c_uint8 * 4), ("castle", C.c_uint8 * 4), ("turn", C.c_uint8), ("pad", C.c_uint8 * 15)]
+
+
+assert C.sizeof(Board) == 288
+
+
+class Move(C.Structure):
+    _fields_ = [("frm", C.c_uint8), ("to", C.c_uint8), ("capture", C.c_uint8), ("promo", C.c_uint8),
+                ("flat", C.c_uint16), ("pad", C.c_uint16)]
+
+
+class Config(C.Structure):
+    _fields_ = [("board_size", C.c_int), ("invalid_area", C.c_int), ("max_games", C.c_int), ("max_sims", C.c_int),
+                ("avg_children", C.c_int), ("device", C.c_int), ("nn_dtype", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("ms_select", C.c_double), ("ms_nn", C.c_double), ("ms_expand", C.c_double),
+                ("launches_select", C.c_uint64), ("launches_nn", C.c_uint64), ("launches_expand", C.c_uint64),
+                ("sims", C.c_uint64), ("nodes", C.c_uint64)]
+
+
+P = C.POINTER
+_SIGS = {
+    "fpc_abi_version": (C.c_int, []),
+    "fpc_create": (C.c_int, [P(Config), P(C.c_void_p)]),
+    "fpc_destroy": (None, [C.c_void_p]),
+    "fpc_last_error": (C.c_char_p, [C.c_void_p]),
+    "fpc_num_action_channels": (C.c_int, [C.c_int]),
+    "fpc_action_space_size": (C.c_int, [C.c_int]),
+    "fpc_is_legal_location": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "fpc_move_flat_index": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "fpc_flat_to_move": (C.c_int, [C.c_int, C.c_int, P(C.c_int), P(C.c_int)]),
+    "fpc_board_from_dict": (C.c_int, [P(Board), C.c_int, C.c_int, P(C.c_uint8), P(C.c_uint8), C.c_int, P(C.c_uint8)]),
+    "fpc_board_heuristic": (C.c_int, [P(Board), C.c_int]),
+    "fpc_boards_legal_moves": (C.c_int, [C.c_void_p, P(Board), C.c_int, P(Move), P(C.c_int)]),
+    "fpc_boards_game_result": (C.c_int, [C.c_void_p, P(Board), C.c_int, P(C.c_int), P(C.c_int)]),
+    "fpc_boards_take_action": (C.c_int, [C.c_void_p, P(Board), P(C.c_int), C.c_int, P(Board)]),
+    "fpc_boards_encode": (C.c_int, [C.c_void_p, P(Board), C.c_int, C.c_void_p]),
+    "fpc_boards_legal_mask": (C.c_int, [C.c_void_p, P(Board), C.c_int, C.c_void_p]),
+    "fpc_search_begin": (C.c_int, [C.c_void_p, P(Board), C.c_int, C.c_double]),
+    "fpc_search_select": (C.c_int, [C.c_void_p, P(C.c_int), P(C.c_void_p)]),
+    "fpc_search_expand": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fpc_search_run": (C.c_int, [C.c_void_p, C.c_int]),
+    "fpc_search_results": (C.c_int, [C.c_void_p, P(Board), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fpc_search_grandchildren": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, P(C.c_int), C.c_void_p, C.c_void_p]),
+    "fpc_load_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "fpc_nn_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "fpc_stats_get": (C.c_int, [C.c_void_p, P(Stats)]),
+    "fpc_stats_reset": (C.c_int, [C.c_void_p]),
+    "fpc_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "fpc_stream": (C.c_void_p, [C.c_void_p]),
+}
+EXPORTS = sorted(_SIGS)
+
+
+def bind(cdll):
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(cdll, name)     # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+_lib = None
+
+
+def lib():
+    """The product library.  Raises if it has not been built (python __graft_entry__.py)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("HIP engine library missing: %s (build it with `python __graft_entry__.py`); "
+                               "there is no CPU fallback" % LIB_PATH)
+        # PyTorch-ROCm ships its own libamdhip64.so.7; it must be the copy already mapped when the
+        # engine library is loaded, otherwise two HIP runtimes end up in one process and the second
+        # one to initialise sees no GPU.  torch is plumbing here (device tensors for the evaluator
+        # seam, torch.distributed), not a compute path.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        _lib = bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def clone_board(b):
+    nb = Board()
+    C.memmove(C.byref(nb), C.byref(b), C.sizeof(Board))
+    return nb
+
+
+class Engine:
+    """One engine handle == one GPU.  Thin, allocation-free-on-the-hot-path wrapper over the C-ABI."""
+
+    def __init__(self, board_size, invalid_area, max_games=256, max_sims=400, avg_children=0, device=0, nn_dtype=0,
+                 _lib=None):
+        self.L = _lib if _lib is not None else lib()
+        self.R, self.INV = board_size, invalid_area
+        self.A_ch = self.L.fpc_num_action_channels(board_size)
+        self.A = self.L.fpc_action_space_size(board_size)
+        self.max_games, self.max_sims = max_games, max_sims
+        cfg = Config(board_size, invalid_area, max_games, max_sims, avg_children, device, nn_dtype)
+        h = C.c_void_p()
+        rc = self.L.fpc_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("fpc_create failed (%d): %s" % (rc, (self.L.fpc_last_error(None) or b"").decode()))
+        self.h = h
+        self.G = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fpc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError((self.L.fpc_last_error(self.h) or b"").decode() or ("fpc error %d" % rc))
+
+    # ---- batched position ops (boards: list of Board, mutated in place like the reference) ----
+    @staticmethod
+    def _arr(boards):
+        return (Board * len(boards))(*boards)
+
+    @staticmethod
+    def _writeback(arr, boards):
+        for i, b in enumerate(boards):
+            C.memmove(C.byref(b), C.byref(arr[i]), C.sizeof(Board))
+
+    def legal_moves(self, boards):
+        n = len(boards)
+        arr = self._arr(boards)
+        mv = (Move * (n * MAX_MOVES))()
+        cnt = (C.c_int * n)()
+        self._chk(self.L.fpc_boards_legal_moves(self.h, arr, n, mv, cnt))
+        self._writeback(arr, boards)
+        out = []
+        for i in range(n):
+            out.append([(mv[i * MAX_MOVES + k].frm, mv[i * MAX_MOVES + k].to, mv[i * MAX_MOVES + k].flat,
+                         mv[i * MAX_MOVES + k].promo, mv[i * MAX_MOVES + k].capture) for k in range(cnt[i])])
+        return out
+
+    def game_result(self, boards, players=None):
+        n = len(boards)
+        arr = self._arr(boards)
+        res = (C.c_int * n)()
+        pl = (C.c_int * n)(*players) if players is not None else None
+        self._chk(self.L.fpc_boards_game_result(self.h, arr, n, pl, res))
+        self._writeback(arr, boards)
+        return list(res)
+
+    def take_action(self, boards, flats):
+        n = len(boards)
+        arr = self._arr(boards)
+        out = (Board * n)()
+        fl = (C.c_int * n)(*flats)
+        self._chk(self.L.fpc_boards_take_action(self.h, arr, fl, n, out))
+        return [clone_board(out[i]) for i in range(n)]
+
+    def encode(self, boards):
+        n = len(boards)
+        out = np.zeros((n, 24, self.R, self.R), dtype=np.float32)
+        self._chk(self.L.fpc_boards_encode(self.h, self._arr(boards), n, out.ctypes.data))
+        return out
+
+    def legal_mask(self, boards):
+        n = len(boards)
+        arr = self._arr(boards)
+        out = np.zeros((n, self.A_ch, self.R, self.R), dtype=np.float32)
+        self._chk(self.L.fpc_boards_legal_mask(self.h, arr, n, out.ctypes.data))
+        self._writeback(arr, boards)
+        return out
+
+    # ---- search ----
+    def search_begin(self, roots, c_puct):
+        self.G = len(roots)
+        self._chk(self.L.fpc_search_begin(self.h, self._arr(roots), self.G, float(c_puct)))
+
+    def search_select(self):
+        n = C.c_int()
+        p = C.c_void_p()
+        self._chk(self.L.fpc_search_select(self.h, C.byref(n), C.byref(p)))
+        return n.value, p.value
+
+    def search_expand(self, logits_ptr, value_ptr):
+        self._chk(self.L.fpc_search_expand(self.h, logits_ptr, value_ptr))
+
+    def search_run(self, sims):
+        self._chk(self.L.fpc_search_run(self.h, sims))
+
+    def search_results(self, max_children=256, roots=None):
+        G = self.G
+        rv = np.zeros(G, np.int32); nc = np.zeros(G, np.int32); sd = np.zeros(G, np.int32)
+        cf = np.zeros((G, max_children), np.int32); cv = np.zeros((G, max_children), np.int32)
+        cp = np.zeros((G, max_children), np.float32); cw = np.zeros((G, max_children), np.float64)
+        arr = (Board * G)()
+        self._chk(self.L.fpc_search_results(self.h, arr, rv.ctypes.data, nc.ctypes.data, sd.ctypes.data, max_children,
+                                            cf.ctypes.data, cv.ctypes.data, cp.ctypes.data, cw.ctypes.data))
+        if roots is not None:
+            self._writeback(arr, roots)
+        return {"root_n": rv, "n_children": nc, "sims_done": sd, "flat": cf, "visits": cv, "prior": cp, "w": cw,
+                "boards": [clone_board(arr[g]) for g in range(G)]}
+
+    def grandchildren(self, game, child_idx, max_children=256):
+        n = C.c_int()
+        fl = np.zeros(max_children, np.int32); vi = np.zeros(max_children, np.int32)
+        self._chk(self.L.fpc_search_grandchildren(self.h, game, child_idx, max_children, C.byref(n), fl.ctypes.data,
+                                                  vi.ctypes.data))
+        return [[int(fl[i]), int(vi[i])] for i in range(min(n.value, max_children))]
+
+    def load_weights(self, blob):
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        self._chk(self.L.fpc_load_weights(self.h, buf, len(blob)))
+
+    def nn_forward(self, enc_ptr, n, logits_ptr, value_ptr):
+        self._chk(self.L.fpc_nn_forward(self.h, enc_ptr, n, logits_ptr, value_ptr))
+
+    def stats(self):
+        s = Stats()
+        self.L.fpc_stats_get(self.h, C.byref(s))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def stats_reset(self):
+        self.L.fpc_stats_reset(self.h)
+
+    def set_timing(self, on):
+        self.L.fpc_set_timing(self.h, 1 if on else 0)
+
+
+def board_from_dict(R, turn, entries, castle=None, _lib=None):
+    """entries: [(sq, colour, type), ...] in dict insertion order -> Board with the reference's ctor order."""
+    L = _lib if _lib is not None else lib()
+    n = len(entries)
+    sqs = (C.c_uint8 * max(n, 1))(*[e[0] for e in entries])
+    pcs = (C.c_uint8 * max(n, 1))(*[0x80 | (e[1] << 5) | (e[2] << 2) for e in entries])
+    cs = (C.c_uint8 * 4)(*castle) if castle is not None else None
+    b = Board()
+    rc = L.fpc_board_from_dict(C.byref(b), R, turn, sqs, pcs, n, cs)
+    if rc != 0:
+        raise RuntimeError("fpc_board_from_dict failed (%d)" % rc)
+    return b
+
+
+def board_from_lists(R, turn, pl):
+    """pl: per colour [[sq, type], ...] already in piece-list order (fixture format)."""
+    b = Board()
+    for c in range(4):
+        b.king[c] = NO_SQ
+    b.turn = turn
+    for colour, col in enumerate(pl):
+        for sq, typ in col:
+            b.sq[sq] = 0x80 | (colour << 5) | (typ << 2)
+            b.pl[colour][b.plen[colour]] = sq
+            b.plen[colour] += 1
+            if typ == 5:
+                b.king[colour] = sq
+    return b
+
+
+def lists_of(b):
+    return [[[b.pl[c][i], (b.sq[b.pl[c][i]] >> 2) & 7] for i in range(b.plen[c])] for c in range(4)]

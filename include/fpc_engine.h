@@ -1,0 +1,171 @@
+/*
+ * include/fpc_engine.h -- C-ABI of the MI355X-native batched self-play engine for 4-player chess.
+ *
+ * This is the drop-in boundary for the MCTS.search hot path of jorr3/Alphazero-4-player-chess.
+ * The reference has no C-ABI of its own: its boundary is the pybind11 module `alphazero_cpp`
+ * (/root/reference/src/cpp/wrapper.cpp:15-254) plus three Python files on top of it
+ * (src/py/mcts.py, src/py/four_player_chess_board.py, src/py/fen_parser.py).  Every entry point
+ * below names the reference interface it replaces.  The Python class surface the training loop
+ * uses (Board, Move, Node, MCTS, FourPlayerChess ...) is rebuilt over these entry points by the
+ * ctypes shim in alphazero-4-player-chess_amd/alphazero_cpp.py.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function returns 0 on
+ * success or a negative fpc_status; fpc_last_error() gives the message (the shim raises
+ * RuntimeError, mirroring the exception translator at wrapper.cpp:17-27).  All compute runs on the
+ * GPU; there is no CPU fallback -- without a HIP device fpc_create fails with FPC_ENODEVICE.
+ * One engine handle per GPU / per host thread (thread-compatible, not thread-safe).
+ */
+#ifndef FPC_ENGINE_H_
+#define FPC_ENGINE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPC_MAX_SQ 196      /* 14 x 14 */
+#define FPC_MAX_PL 16       /* pieces per colour kept in a piece list */
+#define FPC_NO_SQ 255
+#define FPC_MAX_MOVES 256   /* pseudo-legal moves per position handled on device (reference buffer: 300, engine/board.h:706) */
+
+typedef enum fpc_status {
+  FPC_OK = 0,
+  FPC_EINVAL = -1,      /* bad argument */
+  FPC_ENODEVICE = -2,   /* no HIP device / HIP runtime failure */
+  FPC_ENOMEM = -3,
+  FPC_ESELECT = -4,     /* node.cpp:72-75 "Failed to select a child." */
+  FPC_EPOLICY = -5,     /* legal policy mass is 0/NaN: the reference expands every index and throws (mcts.py:76,84) */
+  FPC_ECAPACITY = -6,   /* node/board pool or move buffer overflow (reference: abort(), engine/board.h:482-486) */
+  FPC_EMOVE = -7,       /* engine/board.cpp:1046-1054 "piece missing for move" */
+  FPC_EUNSUPPORTED = -8,/* castling rights set (the reference's own FEN path never sets them) */
+  FPC_ESTATE = -9,      /* call sequence error */
+  FPC_EWEIGHTS = -10    /* weight blob malformed / not loaded */
+} fpc_status;
+
+/* chess::GameResult, engine/board.h:438-444 */
+enum { FPC_IN_PROGRESS = 0, FPC_WIN_RY = 1, FPC_WIN_BG = 2, FPC_STALEMATE = 3 };
+
+/*
+ * One position == chess::Board state (engine/board.h:696-706) as a 288-byte POD.
+ * piece byte: 0 = empty, else 0x80 | colour<<5 | type<<2  (engine/board.h:101-104;
+ * colour RED 0 BLUE 1 YELLOW 2 GREEN 3, type PAWN 0 .. KING 5).
+ * pl[c][i] is the square (row*R+col) of the i-th entry of piece_list_[c] IN REFERENCE LIST ORDER:
+ * that order is observable (it decides which move GetGameResult looks at first,
+ * engine/board.cpp:904-925) and is mutated by MakeMove/UndoMove, so it is part of the state.
+ */
+typedef struct fpc_board {
+  uint8_t sq[FPC_MAX_SQ];
+  uint8_t pl[4][FPC_MAX_PL];
+  uint8_t plen[4];
+  uint8_t king[4];         /* king_locations_ (FPC_NO_SQ if captured) */
+  uint8_t castle[4];       /* bit0 kingside, bit1 queenside; must be 0 for device ops */
+  uint8_t turn;
+  uint8_t pad[15];
+} fpc_board;               /* sizeof == 288 */
+
+/* One legal move as the reference's Board::GetLegalMoves() reports it (board.cpp:94-118). */
+typedef struct fpc_move {
+  uint8_t from, to;
+  uint8_t capture;         /* piece byte on `to` (0 none) */
+  uint8_t promo;           /* 1 if the reference emits this move 4x (N,B,R,Q promotion variants, engine/board.cpp:82-88) */
+  uint16_t flat;           /* Move::GetFlatIndex(), move.cpp:100-104 */
+  uint16_t pad;
+} fpc_move;
+
+typedef struct fpc_config {
+  int board_size;          /* rows_ == cols_  : 8 (literal snapshot) or 14      engine/board.h:22-23 */
+  int invalid_area;        /* invalid_area    : 2 or 3                           engine/board.h:24    */
+  int max_games;           /* concurrent games on this GPU (num_parallel_games, alphazero.py:303)    */
+  int max_sims;            /* upper bound for num_searches (mcts.py:36)                              */
+  int avg_children;        /* node pool = 1 + max_sims*avg_children per game; 0 -> default 96        */
+  int device;              /* HIP device ordinal                                                     */
+  int nn_dtype;            /* 0 = bf16, 1 = fp16 (MFMA operand type of the internal ResNet)          */
+} fpc_config;
+
+typedef struct fpc_engine fpc_engine;
+
+int  fpc_create(const fpc_config *cfg, fpc_engine **out);
+void fpc_destroy(fpc_engine *e);
+const char *fpc_last_error(const fpc_engine *e);   /* e may be NULL: last create() failure */
+int  fpc_abi_version(void);
+
+/* ---- static geometry: fpchess::Board statics, board.cpp:9-14 / wrapper.cpp:176-181 ---- */
+int fpc_num_action_channels(int board_size);       /* 4R+4C+8 */
+int fpc_action_space_size(int board_size);
+int fpc_is_legal_location(int board_size, int invalid_area, int row, int col);  /* engine/board.h:647-654 */
+/* fpchess::Move codec, move.cpp:23-104.  fpc_flat_to_move returns FPC_NO_SQ in *to when the
+ * target falls off the board (BoardLocation() "missing"). */
+int fpc_move_flat_index(int board_size, int from, int to);   /* -1: GetIndex() throws */
+int fpc_flat_to_move(int board_size, int flat, int *from, int *to);
+
+/* ---- host-side construction: chess::Board::Board, engine/board.cpp:1172-1248 ----
+ * (sq[i], piece[i]) in python-dict insertion order, exactly what pybind hands the reference ctor.
+ * Reproduces the constructor's piece_list_ order (unordered_map iteration + std::sort). */
+int fpc_board_from_dict(fpc_board *out, int board_size, int turn, const uint8_t *sq, const uint8_t *piece,
+                        int n, const uint8_t *castle4 /* nullable */);
+
+/* ---- batched position kernels (one wavefront per position) -------------------------------
+ * boards[] live in HOST memory; they are uploaded, processed on the GPU and written back
+ * (the reference mutates piece-list order in place in all of these). */
+/* Board::GetLegalMoves  (board.cpp:94-118): moves[i*FPC_MAX_MOVES ..] in reference order */
+int fpc_boards_legal_moves(fpc_engine *e, fpc_board *boards, int n, fpc_move *moves, int *counts);
+/* Board::GetGameResult(opt_player) (engine/board.cpp:891-939); player[i] = -1 -> side to move */
+int fpc_boards_game_result(fpc_engine *e, fpc_board *boards, int n, const int *player, int *results);
+/* Board::TakeAction(Move(flat)) (board.cpp:234-239, move.cpp:39-61): out[i] = copy + MakeMove */
+int fpc_boards_take_action(fpc_engine *e, const fpc_board *boards, const int *flat, int n, fpc_board *out);
+/* Board::GetEncodedStates (board.cpp:305-356): out_host [n,24,R,R] f32, rotated by boards[0].turn */
+int fpc_boards_encode(fpc_engine *e, const fpc_board *boards, int n, float *out_host);
+/* FourPlayerChess.get_legal_moves_mask (four_player_chess_board.py:36-56): out_host [n,A_ch,R,R] f32 */
+int fpc_boards_legal_mask(fpc_engine *e, fpc_board *boards, int n, float *out_host);
+/* Board::CalculateHeuristic (engine/board.cpp:1263-1292), pure host arithmetic on the POD */
+int fpc_board_heuristic(const fpc_board *b, int team);
+
+/* ---- MCTS.search (mcts.py:17-43) ---------------------------------------------------------
+ * begin:   fresh root per game, visit_count = 1 (mcts.py:29-32); roots uploaded once.
+ * Then either drive it step by step with an external evaluator (the reference's
+ * `neural_net(x) -> (logits, value)` seam, mcts.py:65-66):
+ *     for each of num_searches:  fpc_search_select -> evaluator -> fpc_search_expand
+ * or let the engine run all simulations with its internal MFMA ResNet: fpc_search_run. */
+int fpc_search_begin(fpc_engine *e, const fpc_board *roots, int n_games, double c_puct);
+/* get_expandable_leaves + GetEncodedStates (mcts.py:18-26,65): selects one leaf per live game,
+ * handles terminal leaves (node.cpp:31-42), encodes the leaves.  *n_live = leaves to evaluate.
+ * enc_dev: DEVICE pointer, [n_games,24,R,R] f32 (slot g = game g; dead games are all-zero). */
+int fpc_search_select(fpc_engine *e, int *n_live, const float **enc_dev);
+/* softmax/ParseActionspace/mask/renormalise + BackpropagateNodes + ExpandNodes (mcts.py:67-89).
+ * logits_dev [n_games, A] f32 and value_dev [n_games] f32 are DEVICE pointers (slot g = game g). */
+int fpc_search_expand(fpc_engine *e, const float *logits_dev, const float *value_dev);
+/* all `sims` simulations with the internal network (weights from fpc_load_weights) */
+int fpc_search_run(fpc_engine *e, int sims);
+/* Root read-back == what alphazero.py:104-110 reads through Node.GetChildren /
+ * GetMoveMade().GetFlatIndex() / GetVisitCount().  Arrays are [n_games][max_children].
+ * roots_out (nullable): the root states with the piece-list order the search left them in. */
+int fpc_search_results(fpc_engine *e, fpc_board *roots_out, int *root_visits, int *n_children, int *sims_done,
+                       int max_children, int *child_flat, int *child_visits, float *child_prior,
+                       double *child_value_sum);
+/* children of root child `child_idx` of game `game` (second tree level, for parity tests) */
+int fpc_search_grandchildren(fpc_engine *e, int game, int child_idx, int max_children, int *n,
+                             int *flat, int *visits);
+
+/* ---- internal ResNet (net.py:6-63), BN folded, MFMA implicit-GEMM ------------------------ */
+/* blob format: see alphazero-4-player-chess_amd/weights.py (header + folded tensors) */
+int fpc_load_weights(fpc_engine *e, const void *blob, uint64_t nbytes);
+/* forward only: enc_dev [n,24,R,R] f32 -> logits_dev [n,A] f32, value_dev [n] f32 (DEVICE pointers) */
+int fpc_nn_forward(fpc_engine *e, const float *enc_dev, int n, float *logits_dev, float *value_dev);
+
+/* ---- measurement hooks (bench.py) -------------------------------------------------------- */
+typedef struct fpc_stats {
+  double ms_select, ms_nn, ms_expand;   /* HIP-event time accumulated since fpc_stats_reset */
+  uint64_t launches_select, launches_nn, launches_expand;
+  uint64_t sims;                        /* leaf evaluations + terminal backups */
+  uint64_t nodes;                       /* nodes allocated */
+} fpc_stats;
+int fpc_stats_get(fpc_engine *e, fpc_stats *out);
+int fpc_stats_reset(fpc_engine *e);
+int fpc_set_timing(fpc_engine *e, int enabled);  /* HIP events around each stage (adds syncs) */
+void *fpc_stream(fpc_engine *e);                 /* hipStream_t the engine launches on */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPC_ENGINE_H_ */

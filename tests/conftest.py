@@ -4,7 +4,7 @@ import sys
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (REPO, os.path.join(REPO, "tests")):
+for p in (REPO, os.path.join(REPO, "tests"), os.path.join(REPO, "alphazero-4-player-chess_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 

@@ -1,0 +1,141 @@
+// tests/emul/wave_emul.h -- TEST INFRASTRUCTURE ONLY.
+//
+// A lock-step emulator of ONE 64-lane CDNA wavefront per block, so that the CPU test-suite
+// (pytest -m "not gpu", no GPU in the build container) can execute the very same tree-kernel source
+// that hipcc compiles for gfx950 (alphazero-4-player-chess_amd/csrc/fpc_tree_kernels.h).  Each lane
+// is a ucontext fibre; every wave collective (__syncthreads, __ballot, __shfl*) is a rendezvous at
+// which the scheduler switches fibres, which reproduces the SIMT semantics the kernels rely on
+// (uniform control flow around collectives).  Blocks run one after another.
+//
+// This is a model of the HARDWARE, not of the algorithm, and it is never part of the product:
+// libfpc_engine.so is built by hipcc only and has no CPU path.  The emulator build
+// (tests/emul/libfpc_emul.so) exists so host logic + kernel logic get CPU coverage.
+#pragma once
+
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct wemu_dim3 {
+  unsigned x, y, z;
+};
+struct float4 {
+  float x, y, z, w;
+};
+
+namespace wemu {
+constexpr int WAVE = 64;
+struct State {
+  ucontext_t main_ctx;
+  ucontext_t lane_ctx[WAVE];
+  char *stacks[WAVE];
+  bool done[WAVE];
+  int cur;
+  wemu_dim3 block_idx;
+  uint64_t slot[WAVE];
+  std::function<void()> body;
+};
+State &st();
+void barrier();
+void run_grid(int grid, int block, const std::function<void()> &body);
+
+template <class T>
+inline uint64_t to_bits(T v) {
+  uint64_t b = 0;
+  static_assert(sizeof(T) <= 8, "shuffle payload too wide");
+  memcpy(&b, &v, sizeof(T));
+  return b;
+}
+template <class T>
+inline T from_bits(uint64_t b) {
+  T v;
+  memcpy(&v, &b, sizeof(T));
+  return v;
+}
+template <class T>
+inline T exchange(T v, int src) {
+  State &s = st();
+  s.slot[s.cur] = to_bits(v);
+  barrier();
+  const T r = (src >= 0 && src < WAVE) ? from_bits<T>(s.slot[src]) : v;
+  barrier();
+  return r;
+}
+}  // namespace wemu
+
+struct wemu_tid_proxy {
+  struct X {
+    operator unsigned() const { return (unsigned)wemu::st().cur; }
+  } x;
+};
+struct wemu_bid_proxy {
+  struct X {
+    operator unsigned() const { return wemu::st().block_idx.x; }
+  } x;
+};
+static wemu_tid_proxy threadIdx;
+static wemu_bid_proxy blockIdx;
+
+inline void __syncthreads() { wemu::barrier(); }
+inline unsigned long long __ballot(bool p) {
+  wemu::State &s = wemu::st();
+  s.slot[s.cur] = p ? 1 : 0;
+  wemu::barrier();
+  unsigned long long m = 0;
+  for (int i = 0; i < wemu::WAVE; ++i)
+    if (!s.done[i] && s.slot[i]) m |= 1ull << i;
+  wemu::barrier();
+  return m;
+}
+template <class T>
+inline T __shfl(T v, int lane) { return wemu::exchange(v, lane); }
+template <class T>
+inline T __shfl_xor(T v, int mask) { return wemu::exchange(v, wemu::st().cur ^ mask); }
+template <class T>
+inline T __shfl_up(T v, int delta) {
+  const int src = wemu::st().cur - delta;
+  return wemu::exchange(v, src >= 0 ? src : wemu::st().cur);
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+
+// ---- the sliver of the HIP runtime API the host engine uses, mapped onto host memory ------------
+typedef int hipError_t;
+typedef void *hipStream_t;
+typedef void *hipEvent_t;
+enum { hipSuccess = 0 };
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
+inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
+inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipMalloc(void **p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : 2; }
+inline hipError_t hipFree(void *p) { free(p); return 0; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return 0; }
+inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
+inline hipError_t hipGetLastError() { return 0; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
+
+#define FPC_LAUNCH(kernel, grid, block, stream, ...) \
+  wemu::run_grid((int)(grid), (int)(block), [&]() { kernel(__VA_ARGS__); })

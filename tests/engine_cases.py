@@ -1,0 +1,193 @@
+"""Parity cases shared by tests/test_engine_emul.py (CPU, wavefront emulator) and
+tests/test_engine_gpu.py (real MI355X, through libfpc_engine.so).  Every case compares the HIP
+kernels' results with (a) the golden vectors from the real reference and/or (b) the CPU oracle on
+the same inputs -- bit-exact (integer/byte/index work; visit counts; f32 priors; f64 value sums)."""
+import numpy as np
+
+import evaluators
+import fpc_ffi
+from fpc_testlib import expand_promos, gold, make_engine, run_external_search
+from oracle import orc
+
+
+def _orc_board(fb, R):
+    return orc.board_from_lists(R, fb.turn, fpc_ffi.lists_of(fb))
+
+
+def case_static(backend, R):
+    g = gold(R)
+    L = fpc_ffi.lib() if backend == "gpu" else __import__("fpc_testlib").emul_lib()
+    assert L.fpc_num_action_channels(R) == g["A_ch"] and L.fpc_action_space_size(R) == g["A"]
+    for r in range(R):
+        for c in range(R):
+            assert L.fpc_is_legal_location(R, g["INV"], r, c) == g["legal_loc"][r][c]
+    st = g["start"]
+    b = fpc_ffi.board_from_dict(R, st["turn"], [tuple(e) for e in st["dict"]], _lib=L)
+    assert fpc_ffi.lists_of(b) == st["after_ctor"]["pl"]      # constructor order (engine/board.cpp:1209-1247)
+    import ctypes as C
+    for flat, frm, to in g["codec_flat_to_move"]:
+        if flat // (R * R) >= 8 * (R - 1) + 8:
+            continue
+        f, t = C.c_int(), C.c_int()
+        assert L.fpc_flat_to_move(R, flat, C.byref(f), C.byref(t)) == 0
+        assert f.value == frm
+        if t.value == fpc_ffi.NO_SQ:
+            assert to == R * R
+        else:
+            assert t.value == to and L.fpc_move_flat_index(R, frm, to) == flat
+
+
+def case_playouts(backend, R, max_games, max_plies):
+    """Lock-step replay of the recorded reference games, all games batched in one launch per call:
+    GetGameResult -> GetLegalMoves -> encode -> TakeAction, comparing results and piece-list order."""
+    g = gold(R)
+    INV = g["INV"]
+    eng = make_engine(backend, R, INV, max_games=4, max_sims=4)
+    games = g["playouts"][:max_games]
+    boards = [fpc_ffi.board_from_lists(R, gm[0]["before"]["turn"], gm[0]["before"]["pl"]) for gm in games]
+    live = list(range(len(games)))
+    n_pos = n_term = n_child = 0
+    for ply in range(max_plies):
+        live = [i for i in live if ply < len(games[i])]
+        if not live:
+            break
+        recs = [games[i][ply] for i in live]
+        bs = [boards[i] for i in live]
+        for b, rec in zip(bs, recs):
+            assert b.turn == rec["before"]["turn"] and fpc_ffi.lists_of(b) == rec["before"]["pl"]
+        res = eng.game_result(bs)
+        for b, rec, r in zip(bs, recs, res):
+            assert r == rec["result"], (ply, r, rec["result"])
+            assert fpc_ffi.lists_of(b) == rec["after_result"]
+            n_pos += 1
+        cont = [k for k, rec in enumerate(recs) if rec["result"] == 0]
+        n_term += len(recs) - len(cont)
+        if not cont:
+            live = []
+            break
+        bs = [bs[k] for k in cont]
+        recs = [recs[k] for k in cont]
+        live = [live[k] for k in cont]
+        lm = eng.legal_moves(bs)
+        for b, rec, m in zip(bs, recs, lm):
+            assert expand_promos(m) == rec["legal"], ply
+            assert fpc_ffi.lists_of(b) == rec["after_legal"]
+        encs = [k for k, rec in enumerate(recs) if "enc" in rec]
+        for k in encs:
+            e = eng.encode([bs[k]])
+            assert np.nonzero(e.flatten())[0].tolist() == recs[k]["enc"]
+        for b, rec in zip(bs, recs):
+            if "children" in rec and ply % 7 == 0:
+                flats = [c[0] for c in rec["children"]]
+                outs = eng.take_action([b] * len(flats), flats)
+                for nb, (fl, snap) in zip(outs, rec["children"]):
+                    assert nb.turn == snap["turn"] and fpc_ffi.lists_of(nb) == snap["pl"]
+                    n_child += 1
+        nxt = eng.take_action(bs, [rec["pick"] for rec in recs])
+        for i, nb in zip(live, nxt):
+            boards[i] = nb
+    eng.close()
+    return n_pos, n_term, n_child
+
+
+def case_batch_encode(backend, R):
+    g = gold(R)
+    be = g["batch_encode"]
+    eng = make_engine(backend, R, g["INV"], max_games=4, max_sims=4)
+    boards = [fpc_ffi.board_from_lists(R, s["turn"], s["pl"]) for s in be["states"]]
+    e = eng.encode(boards)
+    assert list(e.shape) == be["shape"]
+    assert np.nonzero(e.flatten())[0].tolist() == be["enc"]
+    # legal mask == dense form of the legal list (four_player_chess_board.py:36-56)
+    m = eng.legal_mask([fpc_ffi.clone_board(b) for b in boards])
+    lm = eng.legal_moves([fpc_ffi.clone_board(b) for b in boards])
+    for i in range(len(boards)):
+        assert sorted(set(x[2] for x in lm[i])) == np.nonzero(m[i].flatten())[0].tolist()
+    eng.close()
+
+
+def _compare_search(res, oref, tag):
+    """engine result dict vs oracle result list (bit-exact, including f32 priors and f64 W)."""
+    for gi, o in enumerate(oref):
+        n = int(res["n_children"][gi])
+        assert int(res["root_n"][gi]) == o["root_n"], tag
+        got = [[int(res["flat"][gi, k]), int(res["visits"][gi, k])] for k in range(n)]
+        assert got == o["children"], (tag, gi)
+        assert int(res["sims_done"][gi]) == o["sims_done"], tag
+        assert np.array_equal(res["prior"][gi, :n], o["priors"]), (tag, gi, "priors")
+        assert np.array_equal(res["w"][gi, :n], o["w"]), (tag, gi, "value sums")
+        assert fpc_ffi.lists_of(res["boards"][gi]) == orc.lists_of(o["board"]), (tag, gi, "root list order")
+
+
+def case_search_golden(backend, R, max_sims, kinds=None, max_cases=None):
+    """MCTS.search visit counts (root + second level) vs the golden vectors of the real reference and
+    vs the oracle."""
+    g = gold(R)
+    INV = g["INV"]
+    done = 0
+    for si, rec in enumerate(g["searches"]):
+        if rec["sims"] > max_sims or (kinds and rec["kind"] not in kinds):
+            continue
+        if max_cases is not None and done >= max_cases:
+            break
+        done += 1
+        ev = evaluators.make(rec["kind"], R)
+        roots = [fpc_ffi.board_from_lists(R, s["turn"], s["pl"]) for s in rec["before"]]
+        eng = make_engine(backend, R, INV, max_games=len(roots), max_sims=rec["sims"])
+        res = run_external_search(eng, backend, roots, rec["sims"], rec["C"], ev)
+        tag = (si, rec["kind"], rec["sims"])
+        for gi, ref in enumerate(rec["roots"]):
+            n = int(res["n_children"][gi])
+            got = [[int(res["flat"][gi, k]), int(res["visits"][gi, k])] for k in range(n)]
+            assert int(res["root_n"][gi]) == ref["root_n"], tag
+            assert got == [[c[0], c[1]] for c in ref["children"]], (tag, gi)
+            assert fpc_ffi.lists_of(roots[gi]) == ref["after"], (tag, gi)
+            for k, c in enumerate(ref["children"]):
+                if len(c) > 2 and (k % 5 == 0):
+                    assert eng.grandchildren(gi, k) == c[2], (tag, gi, k)
+        oboards = [orc.board_from_lists(R, s["turn"], s["pl"]) for s in rec["before"]]
+        rc, oref = orc.search(oboards, R, INV, rec["sims"], rec["C"], rec["kind"] if rec["kind"] in ("zero", "ramp") else ev)
+        assert rc == 0
+        _compare_search(res, oref, tag)
+        eng.close()
+    return done
+
+
+def case_search_random_vs_oracle(backend, R, n_games, sims, seed, kind="hash"):
+    """Seeded mid-game positions (random playouts through the ORACLE), searched by both sides."""
+    g = gold(R)
+    INV = g["INV"]
+    import random
+    rng = random.Random(seed)
+    st = g["start"]
+    roots_o = []
+    for _ in range(n_games):
+        b = orc.board_from_dict(R, st["turn"], st["dict"])
+        for _ply in range(rng.randrange(0, 40)):
+            if orc.game_result(b, R, INV) != 0:
+                break
+            lm = orc.legal_moves(b, R, INV)
+            flats = sorted(set(x[2] for x in lm))
+            nb, rc = orc.take_action(b, R, flats[rng.randrange(len(flats))])
+            assert rc == 0
+            b = nb
+        if orc.game_result(orc.clone(b), R, INV) != 0:
+            b = orc.board_from_dict(R, st["turn"], st["dict"])
+        roots_o.append(b)
+    roots = [fpc_ffi.board_from_lists(R, b.turn, orc.lists_of(b)) for b in roots_o]
+    ev = evaluators.make(kind, R)
+    rc, oref = orc.search([orc.clone(b) for b in roots_o], R, INV, sims, 3.0, ev)
+    eng = make_engine(backend, R, INV, max_games=n_games, max_sims=sims)
+    if rc == -3:
+        # some leaf had every legal move at probability 0: the reference expands all A indices and
+        # throws "piece missing" (mcts.py:76,84; engine/board.cpp:1046); the engine must refuse too
+        import pytest
+        with pytest.raises(RuntimeError, match="policy mass"):
+            run_external_search(eng, backend, roots, sims, 3.0, ev)
+        eng.close()
+        return "policy-error"
+    assert rc == 0
+    res = run_external_search(eng, backend, roots, sims, 3.0, ev)
+    _compare_search(res, oref, ("random", R, seed))
+    eng.close()
+    return "ok"

@@ -1,0 +1,33 @@
+"""CPU coverage of the product's tree-kernel source + host engine, executed on the 64-lane
+wavefront emulator (tests/emul/).  Same cases as tests/test_engine_gpu.py, smaller sizes."""
+import pytest
+
+import engine_cases as ec
+
+
+@pytest.mark.parametrize("R", [8, 14])
+def test_static(R):
+    ec.case_static("emul", R)
+
+
+@pytest.mark.parametrize("R,games,plies", [(8, 6, 60), (14, 3, 24)])
+def test_playouts(R, games, plies):
+    n_pos, n_term, n_child = ec.case_playouts("emul", R, games, plies)
+    assert n_pos > 50
+
+
+@pytest.mark.parametrize("R", [8, 14])
+def test_batch_encode(R):
+    ec.case_batch_encode("emul", R)
+
+
+def test_search_golden_r8():
+    assert ec.case_search_golden("emul", 8, max_sims=100) >= 6
+
+
+def test_search_golden_r14():
+    assert ec.case_search_golden("emul", 14, max_sims=100, max_cases=3) >= 3
+
+
+def test_search_random_vs_oracle():
+    ec.case_search_random_vs_oracle("emul", 8, n_games=5, sims=40, seed=11)

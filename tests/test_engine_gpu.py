@@ -1,0 +1,36 @@
+"""Parity tests proper: the HIP kernels on a real MI355X, called through the C-ABI
+(libfpc_engine.so), against the golden vectors of the real reference and the CPU oracle."""
+import pytest
+
+import engine_cases as ec
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("R", [8, 14])
+def test_static(R):
+    ec.case_static("gpu", R)
+
+
+@pytest.mark.parametrize("R,games,plies", [(8, 24, 200), (14, 10, 160)])
+def test_playouts_full(R, games, plies):
+    n_pos, n_term, n_child = ec.case_playouts("gpu", R, games, plies)
+    print("positions", n_pos, "terminal", n_term, "children", n_child)
+    assert n_pos > (3000 if R == 8 else 1500)
+
+
+@pytest.mark.parametrize("R", [8, 14])
+def test_batch_encode(R):
+    ec.case_batch_encode("gpu", R)
+
+
+@pytest.mark.parametrize("R", [8, 14])
+def test_search_golden(R):
+    n = ec.case_search_golden("gpu", R, max_sims=400)
+    assert n >= 10
+
+
+@pytest.mark.parametrize("R,games,sims,seed,kind", [(8, 64, 200, 1, "hash"), (14, 48, 150, 2, "hash"),
+                                                    (14, 32, 100, 3, "ramp"), (8, 32, 120, 4, "hashinf")])
+def test_search_random_vs_oracle(R, games, sims, seed, kind):
+    ec.case_search_random_vs_oracle("gpu", R, n_games=games, sims=sims, seed=seed, kind=kind)

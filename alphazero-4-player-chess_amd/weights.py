@@ -1,0 +1,85 @@
+"""Export of a ResNet (net.py here, or the reference's net.py -- same parameter names) into the
+flat weight blob the engine's MFMA kernels consume (format: csrc/fpc_nn.h "weight blob").
+
+eval()-mode BatchNorm is folded into the preceding conv (the search runs under model.eval() +
+torch.no_grad(), alphazero.py:262 / mcts.py:15):   w' = w * g/sqrt(var+eps),  b' = (b-mean)*g/sqrt(var+eps)+beta.
+Conv weights go to [tap][Cout_pad][Cin_pad] (K contiguous); the policy Linear's input axis is
+permuted from the reference's NCHW flatten (ch*R*R + pos) to the engine's NHWC flatten
+(pos*A_ch + ch) and both axes are zero-padded to tile multiples."""
+import struct
+
+import numpy as np
+import torch
+
+
+def _fold(conv, bn):
+    w = conv.weight.detach().float()
+    b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0])
+    s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    return w * s.view(-1, 1, 1, 1), (b - bn.running_mean.detach().float()) * s + bn.bias.detach().float()
+
+
+def _to16(t, dtype):
+    t = t.contiguous()
+    if dtype == 0:
+        return t.to(torch.bfloat16).view(torch.int16).numpy().tobytes()
+    return t.to(torch.float16).view(torch.int16).numpy().tobytes()
+
+
+def _conv_section(w, b, cin_pad, cout_pad, dtype):
+    cout, cin = w.shape[0], w.shape[1]
+    wt = torch.zeros(9, cout_pad, cin_pad)
+    wt[:, :cout, :cin] = w.permute(2, 3, 0, 1).reshape(9, cout, cin)     # tap = ky*3+kx
+    bb = torch.zeros(cout_pad)
+    bb[:cout] = b
+    return [_to16(wt, dtype), bb.numpy().astype(np.float32).tobytes()]
+
+
+def export_weights(model, dtype=0):
+    """model: ResNet in eval semantics.  dtype 0 = bf16, 1 = fp16.  Returns bytes."""
+    model = model.cpu()
+    F = model.startBlock[0].weight.shape[0]
+    nblocks = len(model.backBone)
+    A_ch = model.policyHead[0].weight.shape[0]
+    fc = model.policyHead[4]
+    A = fc.weight.shape[0]
+    RR = A // A_ch
+    R = int(round(RR ** 0.5))
+    assert R * R == RR and fc.weight.shape[1] == A
+    Np = (A + 127) // 128 * 128
+    Kp = (A + 63) // 64 * 64
+    secs = []
+    w, b = _fold(model.startBlock[0], model.startBlock[1])
+    Fp = (F + 127) // 128 * 128
+    secs += _conv_section(w, b, 32, Fp, dtype)
+    for blk in model.backBone:
+        w, b = _fold(blk.conv1, blk.bn1)
+        secs += _conv_section(w, b, F, Fp, dtype)
+        w, b = _fold(blk.conv2, blk.bn2)
+        secs += _conv_section(w, b, F, Fp, dtype)
+    w, b = _fold(model.policyHead[0], model.policyHead[1])
+    secs += _conv_section(w, b, F, 128, dtype)
+    w, b = _fold(model.valueHead[0], model.valueHead[1])
+    secs += _conv_section(w, b, F, 128, dtype)
+    # policy Linear: in index ch*RR+pos -> pos*A_ch+ch ; pad to [Np][Kp]
+    fw = fc.weight.detach().float().view(A, A_ch, RR).permute(0, 2, 1).reshape(A, A)
+    t16 = torch.bfloat16 if dtype == 0 else torch.float16
+    fwp = torch.zeros(Np, Kp, dtype=t16)
+    fwp[:A, :A] = fw.to(t16)
+    del fw
+    secs.append(fwp.view(torch.int16).numpy().tobytes())
+    del fwp
+    fb = np.zeros(Np, np.float32)
+    fb[:A] = fc.bias.detach().float().numpy()
+    secs.append(fb.tobytes())
+    vfc = model.valueHead[4]
+    vw = torch.zeros(RR, 32)
+    vw[:, :24] = vfc.weight.detach().float().view(24, RR).t()
+    secs.append(vw.numpy().astype(np.float32).tobytes())
+    secs.append(struct.pack("<f", float(vfc.bias.detach().float().item())))
+    out = bytearray(struct.pack("<4s8i28x", b"FPCW", 1, R, F, nblocks, dtype, A_ch, Np, Kp))
+    assert len(out) == 64
+    for s in secs:
+        out += b"\0" * ((-len(out)) % 64)
+        out += s
+    return bytes(out)

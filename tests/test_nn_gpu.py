@@ -1,0 +1,116 @@
+"""The MFMA ResNet (csrc/fpc_nn.h) against a plain PyTorch fp32 CPU reference of the same
+architecture (net.py mirrors /root/reference/src/py/net.py:6-63), and the fused device-resident
+search loop against the parity-checked step-wise path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import fpc_ffi
+from fpc_testlib import gold, make_engine, run_external_search
+
+pytestmark = pytest.mark.gpu
+
+
+class Spec:
+    """the gameType attributes net.ResNet reads (wrapper.cpp:176-181, :209-210)"""
+    def __init__(self, R):
+        self.R = R
+        self.num_state_channels = 24
+        self.num_action_channels = 8 * R + 8
+        self.action_space_size = self.num_action_channels * R * R
+        self.state_space_size = 24 * R * R
+
+    def nRows(self):
+        return self.R
+
+    def nCols(self):
+        return self.R
+
+
+def _model(R, blocks, hidden, seed=0):
+    import torch
+    import net
+    torch.manual_seed(seed)
+    m = net.ResNet(Spec(R), blocks, hidden, "cpu")
+    g = torch.Generator().manual_seed(seed + 1)
+    for mod in m.modules():                      # non-trivial BN statistics so that the fold is exercised
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.num_features, generator=g) * 0.5 + 0.75)
+            mod.weight.data.copy_(torch.rand(mod.num_features, generator=g) * 0.5 + 0.75)
+            mod.bias.data.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+    return m.eval()
+
+
+def _positions(R, n):
+    g = gold(R)
+    out = []
+    for game in g["playouts"]:
+        for rec in game[::7]:
+            out.append(fpc_ffi.board_from_lists(R, rec["before"]["turn"], rec["before"]["pl"]))
+            if len(out) == n:
+                return out
+    return out
+
+
+@pytest.mark.parametrize("R,blocks,hidden,dtype,tol", [(8, 4, 64, 1, 1e-3), (8, 4, 64, 0, 8e-3), (8, 2, 128, 1, 1e-3),
+                                                       (14, 2, 64, 1, 1e-3), (14, 2, 64, 0, 8e-3)])
+def test_resnet_forward_vs_torch_fp32(R, blocks, hidden, dtype, tol):
+    """north_star tolerance: policy/value logits within 1e-3 of the fp32 reference.  Met with fp16
+    MFMA operands; bf16 (8 mantissa bits) is reported with its own, looser, bound."""
+    import torch
+    import weights
+    m = _model(R, blocks, hidden)
+    eng = make_engine("gpu", R, gold(R)["INV"], max_games=40, max_sims=4, nn_dtype=dtype)
+    eng.load_weights(weights.export_weights(m, dtype))
+    boards = _positions(R, 37)
+    n = len(boards)
+    enc = np.concatenate([eng.encode([b]) for b in boards])          # per-position rotation
+    with torch.no_grad():
+        ref_l, ref_v = m(torch.from_numpy(enc))
+    x = torch.from_numpy(enc).cuda()
+    lg = torch.empty(n, eng.A, device="cuda")
+    va = torch.empty(n, device="cuda")
+    torch.cuda.synchronize()
+    eng.nn_forward(x.data_ptr(), n, lg.data_ptr(), va.data_ptr())
+    el = (lg.cpu() - ref_l).abs().max().item()
+    ev = (va.cpu() - ref_v.squeeze(1)).abs().max().item()
+    print("R=%d blocks=%d hidden=%d dtype=%s: max|dlogit|=%.3e max|dvalue|=%.3e (logit range %.3f)" % (
+        R, blocks, hidden, "fp16" if dtype else "bf16", el, ev, ref_l.abs().max().item()))
+    assert el < tol and ev < tol
+    eng.close()
+
+
+@pytest.mark.parametrize("R,dtype", [(8, 0), (14, 1)])
+def test_fused_search_equals_stepwise(R, dtype):
+    """fpc_search_run (encode->MFMA net->expand, no host round trip) must give exactly the visit
+    counts of the step-wise path fed with the same network's outputs."""
+    import torch
+    import weights
+    m = _model(R, 2, 64, seed=3)
+    G, sims = 12, 48
+    eng = make_engine("gpu", R, gold(R)["INV"], max_games=G, max_sims=sims, nn_dtype=dtype)
+    eng.load_weights(weights.export_weights(m, dtype))
+    boards = _positions(R, G)
+    roots_a = [fpc_ffi.clone_board(b) for b in boards]
+    eng.search_begin(roots_a, 3.0)
+    eng.search_run(sims)
+    res_a = eng.search_results(roots=roots_a)
+
+    def ev(enc):
+        x = torch.from_numpy(np.ascontiguousarray(enc)).cuda()
+        lg = torch.empty(G, eng.A, device="cuda")
+        va = torch.empty(G, device="cuda")
+        torch.cuda.synchronize()
+        eng.nn_forward(x.data_ptr(), G, lg.data_ptr(), va.data_ptr())
+        return lg.cpu().numpy(), va.cpu().numpy()
+
+    roots_b = [fpc_ffi.clone_board(b) for b in boards]
+    res_b = run_external_search(eng, "gpu", roots_b, sims, 3.0, ev)
+    for k in ("root_n", "n_children", "sims_done", "flat", "visits", "prior", "w"):
+        assert np.array_equal(res_a[k], res_b[k]), k
+    for a, b in zip(roots_a, roots_b):
+        assert bytes(a) == bytes(b)
+    assert int(res_a["sims_done"].sum()) > G * sims // 2
+    eng.close()

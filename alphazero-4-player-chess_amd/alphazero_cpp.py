@@ -1,0 +1,575 @@
+"""`alphazero_cpp` -- drop-in for the reference's pybind11 module of the same name
+(/root/reference/src/cpp/wrapper.cpp:15-254), rebuilt over the C-ABI of the MI355X engine
+(include/fpc_engine.h, libfpc_engine.so).  Put this directory on sys.path exactly like the
+reference's build directory: `from alphazero_cpp import Board, Move, Node, ...` keeps working.
+
+What is different by design: a Python `Board` is a 288-byte POD snapshot (fpc_ffi.Board) and every
+game-logic call (GetLegalMoves, GetGameResult, TakeAction, encode, masks) is one wavefront on the
+GPU; the MCTS tree lives in device memory, `Node` objects are read-only views of search results.
+There is no CPU fallback: without the HIP library / a GPU these calls raise RuntimeError.
+
+Board size: the reference fixes rows_/cols_/invalid_area at compile time (engine/board.h:22-24);
+here it is chosen at import from FPC_BOARD_SIZE (8 -> 8x8/2, the literal snapshot; 14 -> 14x14/3,
+default) or later with configure() before any Board exists.
+"""
+import enum
+import os
+
+import fpc_ffi as _ffi
+
+__all__ = []
+
+
+def _export(cls):
+    for m in cls:
+        globals()[m.name] = m
+        __all__.append(m.name)
+    __all__.append(cls.__name__)
+    return cls
+
+
+@_export
+class PieceType(enum.IntEnum):          # wrapper.cpp:32-40
+    PAWN = 0
+    KNIGHT = 1
+    BISHOP = 2
+    ROOK = 3
+    QUEEN = 4
+    KING = 5
+    NO_PIECE = 6
+
+
+@_export
+class PlayerColor(enum.IntEnum):        # wrapper.cpp:45-51
+    UNINITIALIZED_PLAYER = -1
+    RED = 0
+    BLUE = 1
+    YELLOW = 2
+    GREEN = 3
+
+
+@_export
+class Team(enum.IntEnum):               # wrapper.cpp:56-59
+    RED_YELLOW = 0
+    BLUE_GREEN = 1
+
+
+@_export
+class GameResult(enum.IntEnum):         # wrapper.cpp:61-66
+    IN_PROGRESS = 0
+    WIN_RY = 1
+    WIN_BG = 2
+    STALEMATE = 3
+
+
+def piece_value(t):                     # wrapper.cpp:42
+    return int(t)
+
+
+def color_value(c):                     # wrapper.cpp:53
+    return int(c)
+
+
+# ---- board geometry (compile-time constants in the reference) --------------------------------
+_SIZES = {8: 2, 10: 2, 13: 3, 14: 3}
+_R = int(os.environ.get("FPC_BOARD_SIZE", "14"))
+_INV = _SIZES.get(_R, 3)
+_engine = None
+_engine_cap = (0, 0)
+
+
+def configure(board_size, invalid_area=None):
+    """Select the board geometry (the reference recompiles for this).  Call before creating boards."""
+    global _R, _INV, _engine
+    _R = int(board_size)
+    _INV = int(invalid_area) if invalid_area is not None else _SIZES[_R]
+    if _engine is not None:
+        _engine.close()
+        _engine = None
+    _set_statics()
+
+
+def engine(min_games=1, min_sims=1, nn_dtype=None):
+    """The process-wide engine handle (one per GPU); grown on demand."""
+    global _engine, _engine_cap
+    want_dtype = _engine.nn_dtype if (_engine is not None and nn_dtype is None) else (nn_dtype or 0)
+    if _engine is None or _engine_cap[0] < min_games or _engine_cap[1] < min_sims or _engine.nn_dtype != want_dtype:
+        g = max(min_games, _engine_cap[0], 64)
+        s = max(min_sims, _engine_cap[1], 64)
+        if _engine is not None:
+            _engine.close()
+        dev = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("FPC_DEVICE") is None else int(os.environ["FPC_DEVICE"])
+        _engine = _ffi.Engine(_R, _INV, max_games=g, max_sims=s, device=dev, nn_dtype=want_dtype)
+        _engine.nn_dtype = want_dtype
+        _engine.weights_version = None
+        _engine_cap = (g, s)
+    return _engine
+
+
+class Player:                           # engine/board.h:57-81, wrapper.cpp:81-87
+    __hash__ = None
+
+    def __init__(self, color=PlayerColor.UNINITIALIZED_PLAYER):
+        self._c = PlayerColor(int(color))
+
+    def GetColor(self):
+        return self._c
+
+    def GetTeam(self):
+        return Team.RED_YELLOW if self._c in (PlayerColor.RED, PlayerColor.YELLOW) else Team.BLUE_GREEN
+
+    def __eq__(self, o):
+        return isinstance(o, Player) and self._c == o._c
+
+    def __ne__(self, o):
+        return not self == o
+
+    def __repr__(self):
+        return "Player(%s)" % self._c.name
+
+
+_COLOR_STR = {0: "Red", 1: "Blue", 2: "Yellow", 3: "Green"}
+_TYPE_STR = {0: "Pawn", 1: "Knight", 2: "Bishop", 3: "Rook", 4: "Queen", 5: "King"}
+
+
+class Piece:                            # engine/board.h:96-186, wrapper.cpp:89-103
+    __hash__ = None
+
+    def __init__(self, *a):
+        if len(a) == 0:
+            present, color, ptype = False, PlayerColor.RED, PieceType.NO_PIECE
+        elif len(a) == 3:
+            present, color, ptype = bool(a[0]), a[1], a[2]
+        elif len(a) == 2:
+            present, color, ptype = True, (a[0].GetColor() if isinstance(a[0], Player) else a[0]), a[1]
+        else:
+            raise TypeError("Piece(): incompatible constructor arguments")
+        self._bits = ((1 if present else 0) << 7) | ((int(color) & 3) << 5) | ((int(ptype) & 7) << 2)
+
+    @classmethod
+    def _from_byte(cls, b):
+        p = cls()
+        if b & 0x80:
+            p._bits = b & 0xFC
+        return p
+
+    def _byte(self):
+        return self._bits if self._bits & 0x80 else 0
+
+    def Present(self):
+        return bool(self._bits & 0x80)
+
+    def GetColor(self):
+        return PlayerColor((self._bits >> 5) & 3)
+
+    def GetPieceType(self):
+        return PieceType((self._bits >> 2) & 7)
+
+    def GetPlayer(self):
+        return Player(self.GetColor())
+
+    def PieceTypeToStr(self, type):
+        if int(type) not in _TYPE_STR:
+            raise RuntimeError("Unknown piece type")
+        return _TYPE_STR[int(type)]
+
+    def ColorToStr(self, color):
+        if int(color) not in _COLOR_STR:
+            raise RuntimeError("Unknown color")
+        return _COLOR_STR[int(color)]
+
+    def __eq__(self, o):
+        return isinstance(o, Piece) and self._bits == o._bits
+
+    def __ne__(self, o):
+        return not self == o
+
+    def __str__(self):
+        if not self.Present():
+            raise RuntimeError("Missing piece")
+        return self.ColorToStr(self.GetColor()) + " " + self.PieceTypeToStr(self.GetPieceType())
+
+
+class BoardLocation:                    # engine/board.h:190-224, wrapper.cpp:105-115
+    def __init__(self, row=None, col=None):
+        if row is None:
+            self._loc = _R * _R
+        else:
+            row, col = int(row), int(col)
+            self._loc = _R * _R if (row < 0 or row >= _R or col < 0 or col >= _R) else _R * row + col
+
+    @classmethod
+    def _from_sq(cls, sq):
+        b = cls()
+        b._loc = sq if sq < _R * _R else _R * _R
+        return b
+
+    def Present(self):
+        return self._loc < _R * _R
+
+    def GetRow(self):
+        return self._loc // _R
+
+    def GetCol(self):
+        return self._loc % _R
+
+    def _sq(self):
+        return self._loc if self._loc < _R * _R else _ffi.NO_SQ
+
+    def __eq__(self, o):
+        return isinstance(o, BoardLocation) and self._loc == o._loc
+
+    def __hash__(self):
+        return hash(self.GetRow()) ^ hash(self.GetCol())
+
+    def __str__(self):                  # BoardLocation::PrettyStr, engine/board.cpp:1531-1537
+        return "%s%d (%d, %d)" % (chr(ord("a") + self.GetCol()), _R - self.GetRow(), self.GetRow(), self.GetCol())
+
+
+class CastlingRights:                   # engine/board.h:285-328, wrapper.cpp:117-123
+    __hash__ = None
+
+    def __init__(self, *a):
+        if len(a) == 0:
+            self._bits = 0
+        else:
+            self._bits = 0x80 | ((1 if a[0] else 0) << 6) | ((1 if a[1] else 0) << 5)
+
+    def Present(self):
+        return bool(self._bits & 0x80)
+
+    def Kingside(self):
+        return bool(self._bits & 0x40)
+
+    def Queenside(self):
+        return bool(self._bits & 0x20)
+
+    def __eq__(self, o):
+        return isinstance(o, CastlingRights) and self._bits == o._bits
+
+    def __ne__(self, o):
+        return not self == o
+
+
+class PlacedPiece:                      # engine/board.h:446-471, wrapper.cpp:125-131
+    def __init__(self, location=None, piece=None):
+        self._l = location if location is not None else BoardLocation()
+        self._p = piece if piece is not None else Piece()
+
+    def GetLocation(self):
+        return self._l
+
+    def GetPiece(self):
+        return self._p
+
+    def __str__(self):
+        return str(self._p) + " at " + str(self._l)
+
+
+class Move:                             # move.h:23-49, move.cpp:23-104, wrapper.cpp:135-163
+    def __init__(self, *a, **kw):
+        self._from, self._to = BoardLocation(), BoardLocation()
+        self._capture, self._promo = Piece(), PieceType.NO_PIECE
+        if kw:
+            a = tuple(a) + tuple(kw[k] for k in ("flat_index", "action_plane", "from", "c_move", "to") if k in kw)
+        if len(a) == 0:
+            return
+        if len(a) == 1 and isinstance(a[0], Move):
+            o = a[0]
+            self._from, self._to, self._capture, self._promo = o._from, o._to, o._capture, o._promo
+        elif len(a) == 1:                                   # Move(flat_index), move.cpp:39-61
+            import ctypes as C
+            f, t = C.c_int(), C.c_int()
+            flat = int(a[0])
+            if flat < 0 or flat >= Board.action_space_size:
+                raise RuntimeError("flat index out of range")
+            _ffi.lib().fpc_flat_to_move(_R, flat, C.byref(f), C.byref(t))
+            self._from, self._to = BoardLocation._from_sq(f.value), BoardLocation._from_sq(t.value)
+        elif len(a) == 2 and isinstance(a[1], BoardLocation) and not isinstance(a[0], BoardLocation):
+            frm = a[1]                                      # Move(action_plane, from), move.cpp:23-37
+            flat = int(a[0]) * _R * _R + frm.GetRow() * _R + frm.GetCol()
+            m = Move(flat)
+            self._from, self._to = frm, m._to
+        else:                                               # standard / pawn-move constructors
+            self._from, self._to = a[0], a[1]
+            if len(a) > 2 and isinstance(a[2], Piece):
+                self._capture = a[2]
+            if len(a) == 6:
+                self._promo = PieceType(int(a[5]))
+
+    def From(self):
+        return self._from
+
+    def To(self):
+        return self._to
+
+    def GetIndex(self):
+        flat = self.GetFlatIndex()
+        return (flat // (_R * _R), self._from.GetRow(), self._from.GetCol())
+
+    def GetFlatIndex(self):
+        flat = _ffi.lib().fpc_move_flat_index(_R, self._from._sq(), self._to._sq()) if (
+            self._from.Present() and self._to.Present()) else -1
+        if flat < 0:
+            raise RuntimeError("Invalid move: No corresponding action plane index found. Did you initialize move_index_map?")
+        return flat
+
+    def __repr__(self):
+        return "Move: %s -> %s" % (self._from, self._to)
+
+
+class MemoryEntry:                      # board.h:133-140: Board held BY VALUE + the pi tensor
+    def __init__(self, state, action):
+        self.state = state._copy()
+        self.action = action
+
+
+class Node:
+    """Read-only view of a search-tree node kept on the device (node.h:17-79).  Only what the
+    training loop reads is provided (alphazero.py:104-110): GetChildren / GetMoveMade /
+    GetVisitCount / GetState / IsExpanded."""
+
+    def __init__(self, C=0.0, state=None, parent=None, action_taken=None, prior=0.0, visit_count=0):
+        self._C, self._state, self._parent, self._move = C, state, parent, action_taken
+        self._prior, self._n, self._children = prior, visit_count, []
+        self._value_sum = 0.0
+        self._lazy = None
+
+    def GetMoveMade(self):
+        return self._move
+
+    def GetState(self):
+        return self._state
+
+    def GetChildren(self):
+        if self._lazy is not None:
+            eng, game, idx = self._lazy
+            self._lazy = None
+            self._children = [Node(self._C, None, self, Move(fl), 0.0, n) for fl, n in eng.grandchildren(game, idx)]
+        return list(self._children)
+
+    def GetVisitCount(self):
+        return self._n
+
+    def SetVisitCount(self, v):
+        self._n = int(v)
+
+    def IsExpanded(self):
+        return len(self.GetChildren()) > 0
+
+    def _device_only(self, *a, **k):
+        raise RuntimeError("the search tree lives on the GPU: drive it through MCTS.search (mcts.py); "
+                           "per-node SelectChild/Backpropagate/ExpandNodes/ChooseLeaf have no host form")
+
+    SelectChild = Backpropagate = ChooseLeaf = _device_only
+    BackpropagateNodes = ExpandNodes = staticmethod(_device_only)
+
+
+class Board:                            # board.h:18-131, wrapper.cpp:165-226
+    num_state_channels = 24
+
+    def __init__(self, turn=None, location_to_piece=None, castling_rights=None, root_state=None):
+        self._root_node, self._root_state, self._memory = None, root_state, []
+        if turn is None and location_to_piece is None:
+            self._b = _ffi.Board()
+            return
+        entries = [(loc.GetRow() * _R + loc.GetCol(), int(p.GetColor()), int(p.GetPieceType()))
+                   for loc, p in location_to_piece.items()]
+        castle = None
+        if castling_rights:
+            castle = [0, 0, 0, 0]
+            for k, v in castling_rights.items():
+                c = int(k.GetColor()) if isinstance(k, Player) else int(k)
+                castle[c] = (1 if v.Kingside() else 0) | (2 if v.Queenside() else 0)
+        self._b = _ffi.board_from_dict(_R, int(turn.GetColor()), entries, castle)
+
+    # -- helpers
+    def _copy(self):
+        nb = Board.__new__(type(self))
+        nb._b = _ffi.clone_board(self._b)
+        nb._root_node, nb._root_state, nb._memory = self._root_node, self._root_state, list(self._memory)
+        return nb
+
+    @classmethod
+    def _wrap(cls, pod, like=None):
+        nb = Board.__new__(cls if like is None else type(like))
+        nb._b = pod
+        nb._root_node, nb._root_state, nb._memory = None, None, []
+        if like is not None:
+            nb._root_node, nb._root_state, nb._memory = like._root_node, like._root_state, list(like._memory)
+        return nb
+
+    # -- plain accessors
+    def CalculateHeuristic(self, team):
+        return _ffi.lib().fpc_board_heuristic(self._b, int(team))
+
+    def GetTurn(self):
+        return Player(PlayerColor(self._b.turn))
+
+    def SetTurn(self, player):
+        self._b.turn = int(player.GetColor())
+
+    @staticmethod
+    def GetOpponentValue(val):
+        return -val
+
+    def GetPieceAt(self, x, y):
+        if not (0 <= x < _R and 0 <= y < _R):
+            raise RuntimeError("Location out of bounds")
+        return Piece._from_byte(self._b.sq[x * _R + y])
+
+    def GetBoardLocation(self, x, y):
+        if not (0 <= x < _R and 0 <= y < _R):
+            raise RuntimeError("Location out of bounds")
+        return BoardLocation(x, y)
+
+    def GetPieces(self):
+        out = []
+        for c in range(4):
+            out.append([PlacedPiece(BoardLocation._from_sq(self._b.pl[c][i]), Piece._from_byte(self._b.sq[self._b.pl[c][i]]))
+                        for i in range(self._b.plen[c])])
+        return out
+
+    def GetRootNode(self):
+        return self._root_node
+
+    def SetRootNode(self, n):
+        self._root_node = n
+
+    def GetRootState(self):             # board.h:50-58
+        return self._copy() if self._root_state is None else self._root_state
+
+    def SetRootState(self, s):
+        self._root_state = s
+
+    def GetMemory(self):                # board.h:64-72
+        return self._memory if self._root_state is None else self._root_state._memory
+
+    def AppendToMemory(self, entry):    # board.h:74-83
+        (self._memory if self._root_state is None else self._root_state._memory).append(entry)
+
+    # -- GPU-backed game logic
+    def GetGameResult(self, opt_player=None):
+        pl = None if opt_player is None else [int(opt_player.GetColor())]
+        return GameResult(engine().game_result([self._b], pl)[0])
+
+    def IsMoveLegal(self, move):
+        return False                    # the reference's implementation can never return true
+
+    def GetLegalMoves(self):
+        out = []
+        for frm, to, flat, promo, cap in engine().legal_moves([self._b])[0]:
+            kinds = (PieceType.KNIGHT, PieceType.BISHOP, PieceType.ROOK, PieceType.QUEEN) if promo else (PieceType.NO_PIECE,)
+            for k in kinds:             # promotions are emitted 4x (engine/board.cpp:82-88)
+                m = Move()
+                m._from, m._to = BoardLocation._from_sq(frm), BoardLocation._from_sq(to)
+                m._capture, m._promo = Piece._from_byte(cap), k
+                out.append(m)
+        return out
+
+    def TakeAction(self, move):         # board.cpp:234-239: copy, then MakeMove with (from,to) only
+        pod = engine().take_action([self._b], [move.GetFlatIndex()])[0]
+        return Board._wrap(pod, like=self)
+
+    def GetSimpleState(self):
+        raise RuntimeError("GetSimpleState feeds the pygame reviewer only and is outside the engine's scope")
+
+    GetAttackedSquaresPlayers = GetAttackedSquaresTeams = IsAttackedByPlayer = GetSimpleState
+
+    @staticmethod
+    def ParseActionspace(actionspaces_1d, turn):      # board.cpp:257-263
+        import torch
+        v = actionspaces_1d.view(-1, *Board.action_space_dims)
+        return torch.rot90(v, -int(turn.GetColor()), (-2, -1))
+
+    @staticmethod
+    def ChangePerspective(tensor, rotation):          # board.cpp:252-255
+        import torch
+        return torch.rot90(tensor, rotation, (-2, -1))
+
+    @staticmethod
+    def IsLegalLocation(*a):
+        if len(a) == 1:
+            a = (a[0].GetRow(), a[0].GetCol())
+        return bool(_ffi.lib().fpc_is_legal_location(_R, _INV, int(a[0]), int(a[1])))
+
+    @staticmethod
+    def nRows():
+        return _R
+
+    @staticmethod
+    def nCols():
+        return _R
+
+    @staticmethod
+    def invalidArea():
+        return _INV
+
+    @staticmethod
+    def GetOpponent(c):                 # board.cpp:241-250
+        c = c.GetColor() if isinstance(c, Player) else c
+        return PlayerColor((int(c) + 1) % 4)
+
+    @staticmethod
+    def GetEncodedStates(states, device):             # board.cpp:305-356
+        import torch
+        if device not in ("cpu", "gpu", "cuda"):
+            raise RuntimeError("Invalid device argument.")
+        t = torch.from_numpy(engine().encode([s._b for s in states]))
+        return t if device == "cpu" else t.cuda()
+
+    @staticmethod
+    def GetEncodedState(state, device):
+        return Board.GetEncodedStates([state], device)
+
+    @staticmethod
+    def GetLegalMovesIndices(legal_moves, num_moves):  # board.cpp:424-449
+        b, p, r, c = [], [], [], []
+        for bi, moves in enumerate(legal_moves):
+            for m in moves:
+                pl, row, col = m.GetIndex()
+                b.append(bi); p.append(pl); r.append(row); c.append(col)
+        return b, p, r, c
+
+    def __str__(self):                  # operator<<(Board), engine/board.cpp:1429-1467
+        lines = []
+        for i in range(_R):
+            s = (" " if _R - i < 9 else "") + str(_R - i + 1) + ":"
+            for j in range(_R):
+                if Board.IsLegalLocation(i, j):
+                    p = self._b.sq[i * _R + j]
+                    s += " . " if not p & 0x80 else "%d%s " % ((p >> 5) & 3, "PNBRQK"[(p >> 2) & 7])
+                else:
+                    s += "   "
+            lines.append(s)
+        lines.append("   " + "".join(" %s " % chr(ord("a") + j) for j in range(_R)))
+        lines.append("Turn: Player(%s)" % PlayerColor(self._b.turn).name)
+        return "\n".join(lines) + "\n"
+
+
+class BoardPool:                        # board.h:142-203 (vestigial in the reference: always allocates)
+    def __init__(self, poolSize):
+        self.poolSize = poolSize
+
+    def acquire(self, templateBoard):
+        return templateBoard._copy()
+
+    def release(self, board):
+        pass
+
+
+def _set_statics():
+    A_ch = 8 * _R + 8
+    Board.state_space_size = 24 * _R * _R
+    Board.num_action_channels = A_ch
+    Board.action_space_size = A_ch * _R * _R
+    Board.action_space_dims = (A_ch, _R, _R)
+    Board.state_space_dims = (24, _R, _R)
+    Move.num_queen_moves_per_direction = _R - 1
+    Move.num_queen_moves = 8 * (_R - 1)
+    Move.num_knight_moves = 8
+
+
+_set_statics()
+__all__ += ["piece_value", "color_value", "Player", "Piece", "BoardLocation", "CastlingRights", "PlacedPiece", "Move",
+            "MemoryEntry", "Node", "Board", "BoardPool", "configure", "engine"]

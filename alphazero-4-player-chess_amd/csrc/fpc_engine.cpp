@@ -59,7 +59,11 @@ struct fpc_engine {
   // ---- stats
   bool timing = false;
   fpc_stats stats{};
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // asynchronous stage timing: events are only RECORDED on the stream during the search and read
+  // back in fpc_search_results, so enabling it does not serialise the pipeline
+  std::vector<hipEvent_t> evpool;
+  std::vector<int> evtag;          // 0 step start, 1 nn start, 2 expand start, 3 step end
+  size_t evused = 0;
 #ifndef FPC_EMUL
   fpc::NN nn;
 #endif
@@ -165,16 +169,28 @@ struct LocHash {   // std::hash<chess::BoardLocation>, engine/board.h:229-237
   }
 };
 
-void stage_begin(fpc_engine *e, int i) {
-  if (e->timing) (void)hipEventRecord(e->ev[i], e->stream);
-}
-void stage_end(fpc_engine *e, int i, double *acc) {
+void mark(fpc_engine *e, int tag) {
   if (!e->timing) return;
-  (void)hipEventRecord(e->ev[i + 1], e->stream);
-  (void)hipEventSynchronize(e->ev[i + 1]);
-  float ms = 0;
-  (void)hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]);
-  *acc += ms;
+  if (e->evused == e->evpool.size()) {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreate(&ev) != hipSuccess) return;
+    e->evpool.push_back(ev);
+    e->evtag.push_back(0);
+  }
+  e->evtag[e->evused] = tag;
+  (void)hipEventRecord(e->evpool[e->evused], e->stream);
+  e->evused++;
+}
+// call after the stream has been synchronised
+void resolve_marks(fpc_engine *e) {
+  for (size_t i = 0; i + 1 < e->evused; ++i) {
+    const int a = e->evtag[i], b = e->evtag[i + 1];
+    if (b != a + 1) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->evpool[i], e->evpool[i + 1]) != hipSuccess) continue;
+    if (a == 0) e->stats.ms_select += ms; else if (a == 1) e->stats.ms_nn += ms; else e->stats.ms_expand += ms;
+  }
+  e->evused = 0;
 }
 
 }  // namespace
@@ -275,7 +291,6 @@ int fpc_create(const fpc_config *cfg, fpc_engine **out) {
   int r = 0;
   auto bail = [&](int code) { g_create_error = e->err; fpc_destroy(e); return code; };
   if (hipStreamCreate(&e->stream) != hipSuccess) { e->err = "hipStreamCreate failed"; return bail(FPC_ENODEVICE); }
-  for (auto &ev : e->ev) (void)hipEventCreate(&ev);
   const int Gm = cfg->max_games;
   Tree &t = e->t;
   t.node_cap = 1 + cfg->max_sims * e->cfg.avg_children;
@@ -314,7 +329,7 @@ void fpc_destroy(fpc_engine *e) {
   e->nn.destroy();
 #endif
   for (void *p : e->allocs) (void)hipFree(p);
-  for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+  for (auto &ev : e->evpool) if (ev) (void)hipEventDestroy(ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -399,7 +414,7 @@ int fpc_search_begin(fpc_engine *e, const fpc_board *roots, int n_games, double 
 }
 
 static int launch_select(fpc_engine *e) {
-  stage_begin(e, 0);
+  mark(e, 0);
   FPC_LAUNCH(k_select, e->G, 64, e->stream, e->dc, e->t, e->G, e->Cpuct, (const double *)e->d_logtab);
   FPC_LAUNCH(k_leaf_slots, (e->G + 63) / 64, 64, e->stream, e->t, e->G, e->d_leaf_slot);
   return 0;
@@ -412,7 +427,7 @@ int fpc_search_select(fpc_engine *e, int *n_live, const float **enc_dev) {
              (const int *)e->d_leaf_slot, (const int *)e->t.leaf_turn, e->G, 0, e->d_enc_f32, (uint16_t *)nullptr,
              (uint16_t)0, -1);
   HIPCHK(e, hipGetLastError());
-  stage_end(e, 0, &e->stats.ms_select);
+  mark(e, 1);
   e->stats.launches_select++;
   std::vector<int> slots(e->G);
   HIPCHK(e, hipMemcpyAsync(slots.data(), e->d_leaf_slot, (size_t)e->G * sizeof(int), hipMemcpyDeviceToHost, e->stream));
@@ -427,10 +442,10 @@ int fpc_search_select(fpc_engine *e, int *n_live, const float **enc_dev) {
 int fpc_search_expand(fpc_engine *e, const float *logits_dev, const float *value_dev) {
   if (!e || !e->searching) return fail(e, FPC_ESTATE, "fpc_search_begin has not been called");
   if (!logits_dev || !value_dev) return fail(e, FPC_EINVAL, "null logits/value");
-  stage_begin(e, 2);
+  mark(e, 2);
   FPC_LAUNCH(k_expand, e->G, 64, e->stream, e->dc, e->t, e->G, logits_dev, value_dev);
   HIPCHK(e, hipGetLastError());
-  stage_end(e, 2, &e->stats.ms_expand);
+  mark(e, 3);
   e->stats.launches_expand++;
   return 0;
 }
@@ -447,14 +462,12 @@ int fpc_search_run(fpc_engine *e, int sims) {
     FPC_LAUNCH(k_encode, e->G, 64, e->stream, e->dc, (const fpc_board *)e->t.boards, e->t.board_cap,
                (const int *)e->d_leaf_slot, (const int *)e->t.leaf_turn, e->G, 1, (float *)nullptr, e->nn.input16(),
                e->nn.one16(), -1);
-    stage_end(e, 0, &e->stats.ms_select);
-    stage_begin(e, 1);
+    mark(e, 1);
     int r = e->nn.forward(e->G, &e->err);
     if (r) return r;
-    stage_end(e, 1, &e->stats.ms_nn);
-    stage_begin(e, 2);
+    mark(e, 2);
     FPC_LAUNCH(k_expand, e->G, 64, e->stream, e->dc, e->t, e->G, (const float *)e->nn.logits(), (const float *)e->nn.value());
-    stage_end(e, 2, &e->stats.ms_expand);
+    mark(e, 3);
     e->stats.launches_select++; e->stats.launches_nn++; e->stats.launches_expand++;
   }
   HIPCHK(e, hipGetLastError());
@@ -486,6 +499,7 @@ int fpc_search_results(fpc_engine *e, fpc_board *roots_out, int *root_visits, in
   if (child_prior) HIPCHK(e, hipMemcpyAsync(child_prior, e->d_rc_f, need * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   if (child_value_sum) HIPCHK(e, hipMemcpyAsync(child_value_sum, e->d_rc_d, need * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  resolve_marks(e);
   uint64_t sims = 0, nodes = 0;
   for (int g = 0; g < G; ++g) {
     if (root_visits) root_visits[g] = meta[(size_t)g * 3 + 0];

@@ -1,0 +1,112 @@
+"""`MCTS` -- drop-in for the reference's src/py/mcts.py:8-89.
+
+Same constructor and `search(games) -> root nodes` contract; the body (per-simulation Python loop
+over ChooseLeaf / GetEncodedStates / softmax / mask / BackpropagateNodes / ExpandNodes) is replaced
+by the engine:
+
+* `neural_net` is a ResNet (net.py here, or any module with the reference's parameter names):
+  its BN-folded weights are exported once per parameter version and the whole search runs on the
+  GPU (`fpc_search_run`: select -> encode -> MFMA ResNet -> expand, no host round trips).
+* `neural_net` is any other callable with a `.device` attribute (the reference's evaluator seam,
+  mcts.py:65-66; synthetic / recorded evaluators in tests): the engine is driven step-wise and the
+  callable sees the encoded leaves `[G,24,R,R]` and returns `(logits [G,A], value [G,1])`.
+  Difference from the reference: the batch always has one slot per game (finished games are
+  all-zero rows whose outputs are ignored) instead of only the live leaves.
+"""
+import torch
+
+import alphazero_cpp as az
+
+
+def _param_version(model):
+    return (id(model), sum(int(p._version) for p in model.parameters()), sum(int(b._version) for b in model.buffers()),
+            bool(model.training))
+
+
+class _DevPtr:
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+def _is_resnet(m):
+    return isinstance(m, torch.nn.Module) and all(hasattr(m, k) for k in ("startBlock", "backBone", "policyHead", "valueHead"))
+
+
+class MCTS:
+    def __init__(self, gameType, neural_net, args):
+        self.gameType = gameType
+        self.args = args
+        self.neural_net = neural_net
+        self.nn_dtype = int(args.get("nn_dtype", 0)) if hasattr(args, "get") else 0
+        self._native = _is_resnet(neural_net)
+
+    def sync_weights(self, eng):
+        """(re-)export the network into the engine when its parameters changed (optimizer.step)."""
+        import weights
+        ver = _param_version(self.neural_net)
+        if getattr(eng, "weights_version", None) != ver:
+            was_training = self.neural_net.training
+            dev = next(self.neural_net.parameters()).device
+            blob = weights.export_weights(self.neural_net, self.nn_dtype)
+            self.neural_net.to(dev)
+            self.neural_net.train(was_training)
+            eng.load_weights(blob)
+            eng.weights_version = _param_version(self.neural_net)
+
+    @torch.no_grad()
+    def search(self, games):
+        G = len(games)
+        sims = int(self.args["num_searches"])
+        eng = az.engine(G, sims, self.nn_dtype if self._native else None)
+        pods = [g._b for g in games]
+        eng.search_begin(pods, float(self.args["C"]))
+        if self._native:
+            self.sync_weights(eng)
+            eng.search_run(sims)
+        else:
+            self._search_external(eng, G, sims)
+        res = eng.search_results(roots=pods)          # root states keep the piece-list order the search left
+        roots = []
+        for g, game in enumerate(games):
+            root = az.Node(self.args["C"], game, visit_count=int(res["root_n"][g]))
+            for k in range(int(res["n_children"][g])):
+                ch = az.Node(self.args["C"], None, root, az.Move(int(res["flat"][g, k])), float(res["prior"][g, k]),
+                             int(res["visits"][g, k]))
+                ch._value_sum = float(res["w"][g, k])
+                ch._lazy = (eng, g, k)
+                root._children.append(ch)
+            game.SetRootNode(root)
+            roots.append(root)
+        for r in roots:
+            assert len(r._children) > 0                 # mcts.py:40-41
+        return roots
+
+    def _search_external(self, eng, G, sims):
+        dev = str(getattr(self.neural_net, "device", "cpu"))
+        on_gpu = dev.startswith("cuda") or dev == "gpu"
+        host_engine = not torch.cuda.is_available()    # only true for the test-suite's emulator build
+        R, A = eng.R, eng.A
+        keep = None
+        for _ in range(sims):
+            n_live, enc_ptr = eng.search_select()
+            if n_live == 0:
+                continue
+            if host_engine:
+                import ctypes
+                import numpy as np
+                enc = torch.from_numpy(np.ctypeslib.as_array(ctypes.cast(enc_ptr, ctypes.POINTER(ctypes.c_float)),
+                                                             shape=(G, 24, R, R)).copy())
+                logits, value = self.neural_net(enc)
+                logits = logits.to(torch.float32).contiguous().view(G, A)
+                value = value.to(torch.float32).contiguous().view(G)
+            else:
+                enc = torch.as_tensor(_DevPtr(enc_ptr, (G, 24, R, R)), device="cuda")
+                logits, value = self.neural_net(enc if on_gpu else enc.cpu())
+                logits = logits.to(device="cuda", dtype=torch.float32).contiguous().view(G, A)
+                value = value.to(device="cuda", dtype=torch.float32).contiguous().view(G)
+                torch.cuda.synchronize()
+            keep = (logits, value)
+            eng.search_expand(logits.data_ptr(), value.data_ptr())
+            if not host_engine:
+                torch.cuda.synchronize()
+        del keep

@@ -167,6 +167,185 @@ __global__ void __launch_bounds__(256) k_gemm16(GemmArgs g) {
   }
 }
 
+// ================================================================================================
+// k_conv3x3: the 3x3 convolution proper.  One block = 256 consecutive rows of the bordered-grid
+// matrix (at 14x14 exactly one game's 16x16 grid) x 128 output channels.  The block's input rows
+// PLUS a halo of P+1 rows on each side are staged into LDS ONCE per 128-channel slab (74 kB) and all
+// nine taps read them at row offsets (ky-1)*P+(kx-1); only the weights stream through a 3-slot LDS
+// ring (16 kB per stage, register-prefetched two stages ahead).  8 waves (4 along M x 2 along N,
+// 64x64 each, 2 waves per SIMD so one wave's LDS reads hide under the other's MFMAs).
+// The XOR swizzle keys on (row mod 16), so a uniform row shift keeps every ds_read_b128 conflict-free.
+// Epilogue: accumulators are staged as f32 through the (now free) image region, 64 columns at a
+// time, then written row-major with bias + residual + ReLU fused and 16-byte stores; border rows of
+// the grid are never written, so they stay zero for the next layer.
+// ================================================================================================
+struct ConvArgs {
+  const uint16_t *X;     // input grid matrix, base already past the guard rows; row stride ldx
+  const uint16_t *W;     // [9][cout_pad][cin] 16-bit
+  const float *bias;     // [cout_pad]
+  const uint16_t *Res;   // residual (output layout) or null
+  uint16_t *out;
+  int ldx, ldo, cin, cout_pad;
+  int P, R, PP, n_valid, m_valid, mode;   // mode 0: grid output (ReLU, +Res); 1: compact policy layout
+};
+
+constexpr int CONV_BM = 256, CONV_BN = 128, CONV_THREADS = 512, CONV_HMAX = 17;
+
+template <int DT, int CINC>
+__global__ void __launch_bounds__(CONV_THREADS) k_conv3x3(ConvArgs g) {
+  constexpr int BKS = CINC < 64 ? CINC : 64;           // K per weight stage
+  constexpr int KC = CINC / BKS;                       // stages per (slab, tap)
+  constexpr int CHA = CINC / 8;                        // 16-B chunks per image row
+  constexpr int CHB = BKS / 8;
+  constexpr int NB = (CONV_BN * CHB) / CONV_THREADS;   // weight chunks per thread per stage (1 or 2)
+  constexpr int IMG_BYTES = (CONV_BM + 2 * CONV_HMAX) * CINC * 2;
+  constexpr int STAGE_BYTES = CONV_BN * BKS * 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *img = smem;
+  unsigned char *ring = smem + (IMG_BYTES > CONV_BM * 64 * 4 ? IMG_BYTES : CONV_BM * 64 * 4);
+  unsigned char *interior = ring + 3 * STAGE_BYTES;    // [256] row predicate
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * CONV_BM, n0 = blockIdx.y * CONV_BN;
+  const int H = g.P + 1, rows_total = CONV_BM + 2 * H;
+  const int nslab = g.cin / CINC, S = nslab * 9 * KC;
+
+  if (tid < CONV_BM) {
+    const int m = m0 + tid, game = m / g.PP, pos = m % g.PP, pi = pos / g.P, pj = pos % g.P;
+    interior[tid] = (pi >= 1 && pi <= g.R && pj >= 1 && pj <= g.R && game < g.m_valid) ? 1 : 0;
+  }
+
+  u32x4_t rb0[NB], rb1[NB];
+#define FPC_WLOAD(REGS, S_)                                                                          \
+  {                                                                                                  \
+    const int sl_ = (S_) / (9 * KC), tap_ = ((S_) / KC) % 9, kc_ = (S_) % KC;                        \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                 \
+      const int c_ = tid + CONV_THREADS * i, row_ = c_ / CHB, j_ = c_ % CHB;                         \
+      REGS[i] = *reinterpret_cast<const u32x4_t *>(g.W + ((long)tap_ * g.cout_pad + n0 + row_) * g.cin + \
+                                                   sl_ * CINC + kc_ * BKS + j_ * 8);                 \
+    }                                                                                                \
+  }
+#define FPC_WSTORE(REGS, SLOT_)                                                                      \
+  {                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                 \
+      const int c_ = tid + CONV_THREADS * i, row_ = c_ / CHB, j_ = c_ % CHB;                         \
+      *reinterpret_cast<u32x4_t *>(ring + (SLOT_) * STAGE_BYTES + lds_off<BKS>(row_, j_)) = REGS[i]; \
+    }                                                                                                \
+  }
+#define FPC_IMG_LOAD(SLAB_)                                                                          \
+  for (int c_ = tid; c_ < rows_total * CHA; c_ += CONV_THREADS) {                                    \
+    const int row_ = c_ / CHA, j_ = c_ % CHA;                                                        \
+    *reinterpret_cast<u32x4_t *>(img + lds_off<CINC>(row_, j_)) =                                    \
+        *reinterpret_cast<const u32x4_t *>(g.X + (long)(m0 - H + row_) * g.ldx + (SLAB_) * CINC + j_ * 8); \
+  }
+
+  f32x16_t acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+
+  FPC_WLOAD(rb0, 0);
+  if (S > 1) FPC_WLOAD(rb1, 1);
+  FPC_IMG_LOAD(0);
+  FPC_WSTORE(rb0, 0);
+  __syncthreads();
+
+  // one pipeline step: weights of stage s are in ring slot s%3; REGS_NEXT holds stage s+1 (to be
+  // written to its slot after the MFMAs), REGS_FREE receives stage s+2
+#define FPC_STEP(S_, REGS_NEXT, REGS_FREE)                                                           \
+  {                                                                                                  \
+    const int s_ = (S_);                                                                             \
+    const int tap_ = (s_ / KC) % 9, kc_ = s_ % KC;                                                   \
+    if (s_ + 2 < S) FPC_WLOAD(REGS_FREE, s_ + 2);                                                    \
+    const int arow_ = H + (tap_ / 3 - 1) * g.P + (tap_ % 3 - 1) + wm * 64 + (lane & 31);             \
+    const unsigned char *wb_ = ring + (s_ % 3) * STAGE_BYTES;                                        \
+    _Pragma("unroll") for (int ks = 0; ks < BKS / 16; ++ks) {                                        \
+      const int ja_ = kc_ * CHB + ks * 2 + (lane >> 5), jb_ = ks * 2 + (lane >> 5);                  \
+      const u32x4_t fa0 = *reinterpret_cast<const u32x4_t *>(img + lds_off<CINC>(arow_, ja_));       \
+      const u32x4_t fa1 = *reinterpret_cast<const u32x4_t *>(img + lds_off<CINC>(arow_ + 32, ja_));  \
+      const u32x4_t fb0 = *reinterpret_cast<const u32x4_t *>(wb_ + lds_off<BKS>(wn * 64 + (lane & 31), jb_));      \
+      const u32x4_t fb1 = *reinterpret_cast<const u32x4_t *>(wb_ + lds_off<BKS>(wn * 64 + 32 + (lane & 31), jb_)); \
+      acc00 = E16<DT>::mfma(fa0, fb0, acc00);                                                        \
+      acc01 = E16<DT>::mfma(fa0, fb1, acc01);                                                        \
+      acc10 = E16<DT>::mfma(fa1, fb0, acc10);                                                        \
+      acc11 = E16<DT>::mfma(fa1, fb1, acc11);                                                        \
+    }                                                                                                \
+    if (s_ + 1 < S) {                                                                                \
+      if ((s_ + 1) % (9 * KC) == 0) {   /* next stage starts a new 128-channel slab: restage image */ \
+        __syncthreads();                                                                             \
+        FPC_IMG_LOAD((s_ + 1) / (9 * KC));                                                           \
+      }                                                                                              \
+      FPC_WSTORE(REGS_NEXT, (s_ + 1) % 3);                                                           \
+    }                                                                                                \
+    __syncthreads();                                                                                 \
+  }
+  for (int s = 0; s < S; s += 2) {
+    FPC_STEP(s, rb1, rb0);
+    if (s + 1 < S) FPC_STEP(s + 1, rb0, rb1);
+  }
+#undef FPC_STEP
+#undef FPC_WLOAD
+#undef FPC_WSTORE
+#undef FPC_IMG_LOAD
+
+  // ---- epilogue: two column halves of 64 through an f32 [256][64] LDS stage (reuses the image)
+  float *stage = reinterpret_cast<float *>(smem);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (wn == h) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const f32x16_t accv = a == 0 ? (b == 0 ? acc00 : acc01) : (b == 0 ? acc10 : acc11);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            stage[row * 64 + b * 32 + (lane & 31)] = accv[r];
+          }
+        }
+    }
+    __syncthreads();
+    // 256 rows x 8 column groups of 8: 2048 items over 512 threads
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int item = tid + CONV_THREADS * i, row = item >> 3, cg = item & 7;
+      const int n = n0 + h * 64 + cg * 8;
+      if (interior[row] && n < g.n_valid) {
+        const long m = (long)m0 + row;
+        const float4 v0 = *reinterpret_cast<const float4 *>(stage + row * 64 + cg * 8);
+        const float4 v1 = *reinterpret_cast<const float4 *>(stage + row * 64 + cg * 8 + 4);
+        const float4 b0 = *reinterpret_cast<const float4 *>(g.bias + n);
+        const float4 b1 = *reinterpret_cast<const float4 *>(g.bias + n + 4);
+        float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
+        long o;
+        if (g.mode == 0) {
+          o = m * g.ldo + n;
+          if (g.Res) {
+            const u32x4_t rr = *reinterpret_cast<const u32x4_t *>(g.Res + o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              v[2 * k] += E16<DT>::to_f32((uint16_t)(rr[k] & 0xffff));
+              v[2 * k + 1] += E16<DT>::to_f32((uint16_t)(rr[k] >> 16));
+            }
+          }
+        } else {
+          const int game = (int)(m / g.PP), pos = (int)(m % g.PP);
+          const int q = (pos / g.P - 1) * g.R + (pos % g.P - 1);
+          o = (long)game * g.ldo + (long)q * g.n_valid + n;
+        }
+        u32x4_t pk;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float lo = v[2 * k] > 0.f ? v[2 * k] : 0.f, hi = v[2 * k + 1] > 0.f ? v[2 * k + 1] : 0.f;
+          pk[k] = (uint32_t)E16<DT>::from_f32(lo) | ((uint32_t)E16<DT>::from_f32(hi) << 16);
+        }
+        *reinterpret_cast<u32x4_t *>(g.out + o) = pk;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // value head tail: Flatten + Linear(24*R*R -> 1) + Tanh (net.py:33-34) on the value conv output
 template <int DT>
 __global__ void __launch_bounds__(64) k_value_tail(const uint16_t *Y, const float *w, float bias, int P, int R, int PP,
@@ -252,7 +431,7 @@ struct NN {
   int init(const DevCfg &c, int max_games, int nn_dtype, hipStream_t s, std::string *) {
     dc = c; Gmax = max_games; dtype = nn_dtype ? 1 : 0; stream = s;
     P = c.R + 2; PP = P * P;
-    Mrows = ((max_games * PP + GEMM_BM - 1) / GEMM_BM) * GEMM_BM;
+    Mrows = ((max_games * PP + CONV_BM - 1) / CONV_BM) * CONV_BM;
     Gpad = ((max_games + GEMM_BM - 1) / GEMM_BM) * GEMM_BM;
     return 0;
   }
@@ -339,18 +518,44 @@ struct NN {
     return 0;
   }
 
+  template <int DT, int CINC>
+  int launch_conv_c(const ConvArgs &g, int M, std::string *err) {
+    constexpr int BKS = CINC < 64 ? CINC : 64;
+    constexpr int IMG = (CONV_BM + 2 * CONV_HMAX) * CINC * 2;
+    constexpr int lds = (IMG > CONV_BM * 64 * 4 ? IMG : CONV_BM * 64 * 4) + 3 * CONV_BN * BKS * 2 + CONV_BM;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3<DT, CINC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr = true;
+    }
+    dim3 grid(M / CONV_BM, g.cout_pad / CONV_BN), block(CONV_THREADS);
+    hipLaunchKernelGGL((k_conv3x3<DT, CINC>), grid, block, lds, stream, g);
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { *err = std::string("k_conv3x3 launch failed: ") + hipGetErrorString(le); return FPC_ENODEVICE; }
+    return 0;
+  }
+  template <int DT>
+  int launch_conv(const ConvArgs &g, int M, std::string *err) {
+    if (g.P + 1 > CONV_HMAX) { *err = "board too large for the conv halo"; return FPC_EINVAL; }
+    if (g.cin == 32) return launch_conv_c<DT, 32>(g, M, err);
+    if (g.cin == 64) return launch_conv_c<DT, 64>(g, M, err);
+    if (g.cin % 128 == 0) return launch_conv_c<DT, 128>(g, M, err);
+    *err = "unsupported conv input width";
+    return FPC_EINVAL;
+  }
+
   template <int DT>
   int forward_t(int n, float *logits_out, float *value_out, std::string *err) {
     int rc;
-    const int M = ((n * PP + GEMM_BM - 1) / GEMM_BM) * GEMM_BM;
+    const int M = ((n * PP + CONV_BM - 1) / CONV_BM) * CONV_BM;
     auto conv = [&](const ConvW &cw, const uint16_t *in, int in_ld, const uint16_t *res, uint16_t *out, int out_ld, int n_valid, int mode) -> int {
-      GemmArgs g{};
-      g.A = in + (size_t)guard * in_ld; g.B = cw.w; g.bias = cw.b;
+      ConvArgs g{};
+      g.X = in + (size_t)guard * in_ld; g.W = cw.w; g.bias = cw.b;
       g.Res = res ? res + (size_t)guard * out_ld : nullptr;
-      g.out = mode == 1 ? (void *)out : (void *)(out + (size_t)guard * out_ld);
-      g.M = M; g.N_pad = cw.cout_pad; g.K_tap = cw.cin; g.ntaps = 9; g.lda = in_ld; g.ldo = out_ld;
+      g.out = mode == 1 ? out : out + (size_t)guard * out_ld;
+      g.ldx = in_ld; g.ldo = out_ld; g.cin = cw.cin; g.cout_pad = cw.cout_pad;
       g.P = P; g.R = dc.R; g.PP = PP; g.n_valid = n_valid; g.m_valid = n; g.mode = mode;
-      return launch_gemm<DT>(g, cw.cin >= 64 ? 64 : 32, err);
+      return launch_conv<DT>(g, M, err);
     };
     if ((rc = conv(stem, in16, 32, nullptr, act[0], F, F, 0))) return rc;
     int cur = 0;

@@ -49,7 +49,6 @@ struct fpc_engine {
   double Cpuct = 0;
   bool searching = false;
   double *d_logtab = nullptr;
-  int *d_leaf_slot = nullptr;
   float *d_enc_f32 = nullptr;     // [max_games,24,R,R]
   fpc_board *d_roots = nullptr;   // staging [max_games]
   int *d_rc_i = nullptr;          // root-children gather
@@ -302,7 +301,7 @@ int fpc_create(const fpc_config *cfg, fpc_engine **out) {
       (r = dalloc(e, &t.nnodes, Gm)) || (r = dalloc(e, &t.nboards, Gm)) || (r = dalloc(e, &t.alive, Gm)) ||
       (r = dalloc(e, &t.sims_done, Gm)) || (r = dalloc(e, &t.err, Gm)) || (r = dalloc(e, &t.leaf_node, Gm)) ||
       (r = dalloc(e, &t.leaf_turn, Gm)) || (r = dalloc(e, &t.nlegal, Gm)) ||
-      (r = dalloc(e, &t.legal, (size_t)Gm * FPC_MAX_MOVES)) || (r = dalloc(e, &e->d_leaf_slot, Gm)) ||
+      (r = dalloc(e, &t.legal, (size_t)Gm * FPC_MAX_MOVES)) || (r = dalloc(e, &t.leaf_slot, Gm)) ||
       (r = dalloc(e, &e->d_enc_f32, (size_t)Gm * 24 * e->dc.RR)) || (r = dalloc(e, &e->d_roots, Gm)) ||
       (r = dalloc(e, &e->d_logtab, (size_t)cfg->max_sims + 16)))
     return bail(r);
@@ -416,7 +415,6 @@ int fpc_search_begin(fpc_engine *e, const fpc_board *roots, int n_games, double 
 static int launch_select(fpc_engine *e) {
   mark(e, 0);
   FPC_LAUNCH(k_select, e->G, 64, e->stream, e->dc, e->t, e->G, e->Cpuct, (const double *)e->d_logtab);
-  FPC_LAUNCH(k_leaf_slots, (e->G + 63) / 64, 64, e->stream, e->t, e->G, e->d_leaf_slot);
   return 0;
 }
 
@@ -424,13 +422,13 @@ int fpc_search_select(fpc_engine *e, int *n_live, const float **enc_dev) {
   if (!e || !e->searching) return fail(e, FPC_ESTATE, "fpc_search_begin has not been called");
   launch_select(e);
   FPC_LAUNCH(k_encode, e->G, 64, e->stream, e->dc, (const fpc_board *)e->t.boards, e->t.board_cap,
-             (const int *)e->d_leaf_slot, (const int *)e->t.leaf_turn, e->G, 0, e->d_enc_f32, (uint16_t *)nullptr,
+             (const int *)e->t.leaf_slot, (const int *)e->t.leaf_turn, e->G, 0, e->d_enc_f32, (uint16_t *)nullptr,
              (uint16_t)0, -1);
   HIPCHK(e, hipGetLastError());
   mark(e, 1);
   e->stats.launches_select++;
   std::vector<int> slots(e->G);
-  HIPCHK(e, hipMemcpyAsync(slots.data(), e->d_leaf_slot, (size_t)e->G * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipMemcpyAsync(slots.data(), e->t.leaf_slot, (size_t)e->G * sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   int live = 0;
   for (int s : slots) live += s >= 0;
@@ -460,7 +458,7 @@ int fpc_search_run(fpc_engine *e, int sims) {
   for (int s = 0; s < sims; ++s) {
     launch_select(e);
     FPC_LAUNCH(k_encode, e->G, 64, e->stream, e->dc, (const fpc_board *)e->t.boards, e->t.board_cap,
-               (const int *)e->d_leaf_slot, (const int *)e->t.leaf_turn, e->G, 1, (float *)nullptr, e->nn.input16(),
+               (const int *)e->t.leaf_slot, (const int *)e->t.leaf_turn, e->G, 1, (float *)nullptr, e->nn.input16(),
                e->nn.one16(), -1);
     mark(e, 1);
     int r = e->nn.forward(e->G, &e->err);

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -62,6 +63,7 @@ struct GemmArgs {
 };
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128;
+constexpr int FC_SPLITK = 2;
 
 // byte offset of 16-B chunk j of tile row `row` (BK elements per row), XOR-swizzled so that the
 // 16-lane groups of a ds_read_b128 touch 16 distinct 16-B slots of the 256-B bank row
@@ -346,6 +348,441 @@ __global__ void __launch_bounds__(CONV_THREADS) k_conv3x3(ConvArgs g) {
   }
 }
 
+// ================================================================================================
+// k_tower: the whole residual tower (stem + 2*Nb convolutions, F = 128) in ONE launch with the
+// activations of a game never leaving the CU.  One block (8 waves, 2 per SIMD) owns the bordered
+// grids of gpb = 256/PP whole games (one game at 14x14).  LDS (160 KiB exactly):
+//   img  64 kB   the current layer's INPUT image, 256 rows x 128 ch, XOR-swizzled 16-B chunks
+//   ring 96 kB   3 slots x [128 cout][128 cin] = one whole tap of weights per stage (9 stages/layer)
+// The residual x_l lives packed in registers in accumulator layout, so after the last tap of a layer
+// (barrier) the image is dead and the layer's output is written IN PLACE from the accumulators:
+//   conv1: img(x) -> acc -> ReLU -> img(t)        conv2: img(t) -> acc + res -> ReLU -> img(x'), res
+// Both heads' convolutions run as two more layers of the same stream: the value conv (only its 32
+// live output columns are computed) feeds Flatten+Linear+Tanh directly from the accumulators, the
+// policy conv writes ReLU'd 16-bit rows in place and the image is then copied, position-major, into
+// the policy Linear's input matrix.  Weights are L2-resident and register-prefetched two stages ahead straight across layer boundaries.
+// Tap addressing wraps modulo 256 rows: a wrapped row only ever feeds a border output, and border /
+// unused rows are never written, so they stay zero (= the conv's zero padding) for every layer.
+// ================================================================================================
+struct TowerArgs {
+  const uint16_t *in16;   // encoded input grid [rows][32], base past the guard rows
+  const uint16_t *Wstem;  // [9][128][32]
+  const float *bstem;     // [128]
+  const uint16_t *Wt;     // [L][9][128][128]
+  const float *bt;        // [L][128]
+  uint16_t *out;          // final activations, grid layout [rows][128], base past the guard rows (heads == 0)
+  // fused heads (heads == 1): layer L = value conv (24 of 128 cout used), layer L+1 = policy conv
+  uint16_t *xfc;          // compact policy-Linear input [game][Kp]: index q*A_ch + ch
+  const float *vw;        // value Linear weights [R*R][32]
+  float *value;           // [n_games] = tanh(vb + sum relu(vconv) * vw)
+  float vb;
+  int L, P, R, PP, gpb, n_games, heads, Kp, A_ch;
+};
+
+#ifndef FPC_FC_VARIANT
+#define FPC_FC_VARIANT 0      // 1/2: timing experiments (no weight stream / no activation stream); results wrong
+#endif
+#ifndef FPC_TOWER_VARIANT
+#define FPC_TOWER_VARIANT 0   // 1/2: timing experiments (no weight reload / + no stage barrier); results wrong
+#endif
+constexpr int TOWER_F = 128, TOWER_THREADS = 512;
+constexpr int TOWER_IMG = 256 * TOWER_F * 2;            // 65536
+constexpr int TOWER_STAGE = 128 * 128 * 2;              // 32768: one tap
+constexpr int TOWER_LDS = TOWER_IMG + 3 * TOWER_STAGE;  // 163840 = 160 KiB
+
+template <int DT>
+__global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *img = smem, *ring = smem + TOWER_IMG;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int rows_used = g.gpb * g.PP;
+  const long m0 = (long)blockIdx.x * rows_used;
+  const int game0 = blockIdx.x * g.gpb;
+
+  // per-lane interior predicate of its 2 x 16 accumulator rows
+  unsigned rowmask[2] = {0u, 0u};
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int gi = row / g.PP, pos = row % g.PP, pi = pos / g.P, pj = pos % g.P;
+      const bool in = row < rows_used && game0 + gi < g.n_games && pi >= 1 && pi <= g.R && pj >= 1 && pj <= g.R;
+      rowmask[a] |= (in ? 1u : 0u) << r;
+    }
+
+  // zero the image (borders / unused rows must read as zero for every layer)
+  for (int c = tid; c < TOWER_IMG / 16; c += TOWER_THREADS) reinterpret_cast<u32x4_t *>(img)[c] = u32x4_t{0u, 0u, 0u, 0u};
+  // encoded input (32 channels, 64-byte rows) -> ring slot 2, which the stem does not use for weights
+  unsigned char *enc = ring + 2 * TOWER_STAGE;
+  for (int c = tid; c < 256 * 4; c += TOWER_THREADS) {
+    const int row = c >> 2, j = c & 3;
+    u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+    if (row < rows_used) v = *reinterpret_cast<const u32x4_t *>(g.in16 + (m0 + row) * 32 + j * 8);
+    *reinterpret_cast<u32x4_t *>(enc + lds_off<32>(row, j)) = v;
+  }
+
+  f32x16_t acc00, acc01, acc10, acc11;
+#define FPC_ZERO_ACC() \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+  FPC_ZERO_ACC();
+  uint32_t res[2][2][8];          // residual x_l, packed 16-bit pairs (r even | r odd << 16), accumulator layout
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) res[a][b][k] = 0u;
+
+  // epilogue of one layer, from registers, IN PLACE into the image: v = acc + bias (+res); ReLU;
+  // 16-bit at interior rows; KEEP_RES also refreshes the residual registers.
+#define FPC_TOWER_EPI(ADD_RES, KEEP_RES)                                                             \
+  {                                                                                                  \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b) {    \
+      const f32x16_t accv = a == 0 ? (b == 0 ? acc00 : acc01) : (b == 0 ? acc10 : acc11);            \
+      const float bs = b == 0 ? bias0 : bias1;                                                       \
+      const int n_ = wn * 64 + b * 32 + (lane & 31);                                                 \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                               \
+        float v = accv[r] + bs;                                                                      \
+        const uint32_t pr = res[a][b][r >> 1];                                                       \
+        if (ADD_RES) v += E16<DT>::to_f32((uint16_t)((r & 1) ? (pr >> 16) : (pr & 0xffffu)));        \
+        v = v > 0.f ? v : 0.f;                                                                       \
+        const bool in_ = (rowmask[a] >> r) & 1u;                                                     \
+        const uint16_t h = in_ ? E16<DT>::from_f32(v) : (uint16_t)0;                                 \
+        if (KEEP_RES) res[a][b][r >> 1] = (r & 1) ? ((pr & 0xffffu) | ((uint32_t)h << 16)) : ((pr & 0xffff0000u) | h); \
+        if (in_) {                                                                                   \
+          const int row = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);               \
+          *reinterpret_cast<uint16_t *>(img + lds_off<TOWER_F>(row, n_ >> 3) + (n_ & 7) * 2) = h;    \
+        }                                                                                            \
+      }                                                                                              \
+    }                                                                                                \
+  }
+
+  // value head from the accumulators (net.py:28-35): relu(conv + bias)[q][ch] . vw[q][ch], ch < 24
+#define FPC_VALUE_EPI()                                                                              \
+  if (wn == 0 && (lane & 31) < 24) {                                                                 \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                  \
+      const f32x16_t accv = a == 0 ? acc00 : acc10;                                                  \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                               \
+        if ((rowmask[a] >> r) & 1u) {                                                                \
+          const int row = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);               \
+          const int gi = row / g.PP, pos = row % g.PP;                                               \
+          const int q = (pos / g.P - 1) * g.R + (pos % g.P - 1);                                     \
+          float v = accv[r] + bias0;                                                                 \
+          v = v > 0.f ? v : 0.f;                                                                     \
+          v = E16<DT>::to_f32(E16<DT>::from_f32(v));     /* same rounding point as the unfused path */ \
+          const float pv = v * g.vw[q * 32 + (lane & 31)];                                           \
+          if (gi == 0) vsum0 += pv; else vsum1 += pv;                                                \
+        }                                                                                            \
+      }                                                                                              \
+    }                                                                                                \
+  }
+
+  // ---------------- stem: enc(32 ch) -> img, 9 stages of [128][32] through ring slots 0/1 ----------
+  {
+    u32x4_t w0, w1;
+#define FPC_SLOAD(REG, S_) REG = *reinterpret_cast<const u32x4_t *>(g.Wstem + ((long)(S_) * 128 + (tid >> 2)) * 32 + (tid & 3) * 8);
+#define FPC_SSTORE(REG, SLOT_) *reinterpret_cast<u32x4_t *>(ring + (SLOT_) * TOWER_STAGE + lds_off<32>(tid >> 2, tid & 3)) = REG;
+    FPC_SLOAD(w0, 0);
+    FPC_SLOAD(w1, 1);
+    const float bias0 = g.bstem[wn * 64 + (lane & 31)], bias1 = g.bstem[wn * 64 + 32 + (lane & 31)];
+    FPC_SSTORE(w0, 0);
+    __syncthreads();
+#define FPC_SSTEP(S_, REG_NEXT, REG_FREE)                                                            \
+    {                                                                                                \
+      const int s_ = (S_);                                                                           \
+      if (s_ + 2 < 9) FPC_SLOAD(REG_FREE, s_ + 2);                                                   \
+      const int arow_ = (s_ / 3 - 1) * g.P + (s_ % 3 - 1) + wm * 64 + (lane & 31);                   \
+      const unsigned char *wb_ = ring + (s_ & 1) * TOWER_STAGE;                                      \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                             \
+        const int j_ = ks * 2 + (lane >> 5);                                                         \
+        const u32x4_t fa0 = *reinterpret_cast<const u32x4_t *>(enc + lds_off<32>(arow_ & 255, j_));           \
+        const u32x4_t fa1 = *reinterpret_cast<const u32x4_t *>(enc + lds_off<32>((arow_ + 32) & 255, j_));    \
+        const u32x4_t fb0 = *reinterpret_cast<const u32x4_t *>(wb_ + lds_off<32>(wn * 64 + (lane & 31), j_));      \
+        const u32x4_t fb1 = *reinterpret_cast<const u32x4_t *>(wb_ + lds_off<32>(wn * 64 + 32 + (lane & 31), j_)); \
+        acc00 = E16<DT>::mfma(fa0, fb0, acc00); acc01 = E16<DT>::mfma(fa0, fb1, acc01);              \
+        acc10 = E16<DT>::mfma(fa1, fb0, acc10); acc11 = E16<DT>::mfma(fa1, fb1, acc11);              \
+      }                                                                                              \
+      if (s_ + 1 < 9) FPC_SSTORE(REG_NEXT, (s_ + 1) & 1);                                            \
+      __syncthreads();                                                                               \
+    }
+    FPC_SSTEP(0, w1, w0); FPC_SSTEP(1, w0, w1); FPC_SSTEP(2, w1, w0); FPC_SSTEP(3, w0, w1); FPC_SSTEP(4, w1, w0);
+    FPC_SSTEP(5, w0, w1); FPC_SSTEP(6, w1, w0); FPC_SSTEP(7, w0, w1); FPC_SSTEP(8, w1, w0);
+#undef FPC_SSTEP
+#undef FPC_SLOAD
+#undef FPC_SSTORE
+    FPC_TOWER_EPI(false, true);
+    FPC_ZERO_ACC();
+  }
+
+  // ---------------- tower: L layers x 9 stages (one tap = [128 cout][128 cin] per stage) ----------
+  const int total = (g.L + (g.heads ? 2 : 0)) * 9;
+  float vsum0 = 0.f, vsum1 = 0.f;     // value-head partial dot products of this lane (game 0 / 1 of the block)
+  u32x4_t rb0[4], rb1[4];
+#define FPC_TLOAD(REGS, G_)                                                                          \
+  {                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+      const int c_ = tid + TOWER_THREADS * i;                                                        \
+      REGS[i] = *reinterpret_cast<const u32x4_t *>(g.Wt + (long)(G_) * (128 * 128) + (long)c_ * 8);  \
+    }                                                                                                \
+  }
+#define FPC_TSTORE(REGS, SLOT_)                                                                      \
+  {                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+      const int c_ = tid + TOWER_THREADS * i, row_ = c_ >> 4, j_ = c_ & 15;                          \
+      *reinterpret_cast<u32x4_t *>(ring + (SLOT_) * TOWER_STAGE + lds_off<TOWER_F>(row_, j_)) = REGS[i]; \
+    }                                                                                                \
+  }
+  float bias0 = 0.f, bias1 = 0.f;
+  if (total > 0) {
+    FPC_TLOAD(rb0, 0);
+    if (total > 1) FPC_TLOAD(rb1, 1);
+    FPC_TSTORE(rb0, 0);
+  }
+  __syncthreads();
+#define FPC_FRAG(KS_, A0, A1, B0, B1)                                                                \
+  A0 = *reinterpret_cast<const u32x4_t *>(img + lds_off<TOWER_F>(ra0_, (KS_) * 2 + jh_));            \
+  A1 = *reinterpret_cast<const u32x4_t *>(img + lds_off<TOWER_F>(ra1_, (KS_) * 2 + jh_));            \
+  B0 = *reinterpret_cast<const u32x4_t *>(wb_ + lds_off<TOWER_F>(rb0_, (KS_) * 2 + jh_));            \
+  B1 = *reinterpret_cast<const u32x4_t *>(wb_ + lds_off<TOWER_F>(rb1_, (KS_) * 2 + jh_));
+#define FPC_MMA(A0, A1, B0, B1)                                                                      \
+  if (mode_ != 1) {                                                                                  \
+    acc00 = E16<DT>::mfma(A0, B0, acc00); acc01 = E16<DT>::mfma(A0, B1, acc01);                      \
+    acc10 = E16<DT>::mfma(A1, B0, acc10); acc11 = E16<DT>::mfma(A1, B1, acc11);                      \
+  } else if (wn == 0) {   /* value conv: only the 32 live output columns */                          \
+    acc00 = E16<DT>::mfma(A0, B0, acc00); acc10 = E16<DT>::mfma(A1, B0, acc10);                      \
+  }
+#if FPC_TOWER_VARIANT == 3
+#define FPC_FRAGV(KS_, A0, A1, B0, B1) asm volatile("" : "+v"(A0), "+v"(A1), "+v"(B0), "+v"(B1));
+#else
+#define FPC_FRAGV(KS_, A0, A1, B0, B1) FPC_FRAG(KS_, A0, A1, B0, B1)
+#endif
+#define FPC_TSTEP(G_, REGS_NEXT, REGS_FREE, MODE_)   /* MODE_ literal: 0 tower layer, 1 value conv, 2 policy conv */ \
+  {                                                                                                  \
+    const int g_ = (G_), l_ = g_ / 9, tap_ = g_ % 9;                                                 \
+    constexpr int mode_ = (MODE_);                                                                   \
+    if (FPC_TOWER_VARIANT != 1 && FPC_TOWER_VARIANT != 2) { if (g_ + 2 < total) FPC_TLOAD(REGS_FREE, g_ + 2); } \
+    if (tap_ == 0) { bias0 = g.bt[l_ * 128 + wn * 64 + (lane & 31)]; bias1 = g.bt[l_ * 128 + wn * 64 + 32 + (lane & 31)]; } \
+    const int arow_ = (tap_ / 3 - 1) * g.P + (tap_ % 3 - 1) + wm * 64 + (lane & 31);                 \
+    const unsigned char *wb_ = ring + (g_ % 3) * TOWER_STAGE;                                        \
+    /* fragment reads software-pipelined one k-step ahead of the MFMAs that consume them */         \
+    const int ra0_ = arow_ & 255, ra1_ = (arow_ + 32) & 255;                                         \
+    const int rb0_ = wn * 64 + (lane & 31), rb1_ = rb0_ + 32, jh_ = lane >> 5;                       \
+    u32x4_t pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;                                                  \
+    FPC_FRAG(0, pa0, pa1, pb0, pb1);                                                                 \
+    FPC_FRAG(1, qa0, qa1, qb0, qb1);                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAGV(2, pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); \
+    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAGV(3, qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); \
+    FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAGV(4, pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); \
+    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAGV(5, qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); \
+    FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAGV(6, pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); \
+    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAGV(7, qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); \
+    FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0);                                  \
+    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0);                                  \
+    if (FPC_TOWER_VARIANT != 1 && FPC_TOWER_VARIANT != 2) { if (g_ + 1 < total) FPC_TSTORE(REGS_NEXT, (g_ + 1) % 3); } \
+    if (tap_ == 8) {                                                                                 \
+      __syncthreads();               /* every wave is done reading this layer's input image */       \
+      if (mode_ == 1) { FPC_VALUE_EPI(); }                                                           \
+      else if (mode_ == 2) { FPC_TOWER_EPI(false, false); }   /* policy conv: ReLU rows in place */  \
+      else if (l_ & 1) { FPC_TOWER_EPI(true, true); } else { FPC_TOWER_EPI(false, false); }          \
+      FPC_ZERO_ACC();                                                                                \
+    }                                                                                                \
+    if (FPC_TOWER_VARIANT != 2) __syncthreads();                                                     \
+  }
+  const int tower_stages = g.L * 9;            // even
+  for (int gs = 0; gs < tower_stages; gs += 2) {
+    FPC_TSTEP(gs, rb1, rb0, 0);
+    FPC_TSTEP(gs + 1, rb0, rb1, 0);
+  }
+  if (g.heads) {
+    const int v0 = tower_stages, p0 = tower_stages + 9;
+    FPC_TSTEP(v0 + 0, rb1, rb0, 1); FPC_TSTEP(v0 + 1, rb0, rb1, 1); FPC_TSTEP(v0 + 2, rb1, rb0, 1);
+    FPC_TSTEP(v0 + 3, rb0, rb1, 1); FPC_TSTEP(v0 + 4, rb1, rb0, 1); FPC_TSTEP(v0 + 5, rb0, rb1, 1);
+    FPC_TSTEP(v0 + 6, rb1, rb0, 1); FPC_TSTEP(v0 + 7, rb0, rb1, 1); FPC_TSTEP(v0 + 8, rb1, rb0, 1);
+    FPC_TSTEP(p0 + 0, rb0, rb1, 2); FPC_TSTEP(p0 + 1, rb1, rb0, 2); FPC_TSTEP(p0 + 2, rb0, rb1, 2);
+    FPC_TSTEP(p0 + 3, rb1, rb0, 2); FPC_TSTEP(p0 + 4, rb0, rb1, 2); FPC_TSTEP(p0 + 5, rb1, rb0, 2);
+    FPC_TSTEP(p0 + 6, rb0, rb1, 2); FPC_TSTEP(p0 + 7, rb1, rb0, 2); FPC_TSTEP(p0 + 8, rb0, rb1, 2);
+  }
+#undef FPC_TSTEP
+#undef FPC_FRAG
+#undef FPC_FRAGV
+#undef FPC_MMA
+#undef FPC_TLOAD
+#undef FPC_TSTORE
+#undef FPC_TOWER_EPI
+#undef FPC_VALUE_EPI
+#undef FPC_ZERO_ACC
+
+  if (!g.heads) {
+    // final x -> global grid (whole rows: borders are zero in the image)
+    for (int c = tid; c < 256 * 16; c += TOWER_THREADS) {
+      const int row = c >> 4, j = c & 15;
+      if (row < rows_used && game0 + row / g.PP < g.n_games)
+        *reinterpret_cast<u32x4_t *>(g.out + (m0 + row) * TOWER_F + j * 8) = *reinterpret_cast<const u32x4_t *>(img + lds_off<TOWER_F>(row, j));
+    }
+    return;
+  }
+  // policy conv rows (ReLU'd, in the image) -> Linear input, position-major: A_ch*2 bytes per position
+  {
+    const int cpr = g.A_ch / 8;                       // 16-byte chunks per position (A_ch % 8 == 0)
+    for (int c = tid; c < 256 * 16; c += TOWER_THREADS) {
+      const int row = c >> 4, j = c & 15;
+      if (row >= rows_used || j >= cpr) continue;
+      const int gi = row / g.PP, pos = row % g.PP, pi = pos / g.P, pj = pos % g.P;
+      if (game0 + gi >= g.n_games || pi < 1 || pi > g.R || pj < 1 || pj > g.R) continue;
+      const int q = (pi - 1) * g.R + (pj - 1);
+      *reinterpret_cast<u32x4_t *>(g.xfc + (long)(game0 + gi) * g.Kp + (long)q * g.A_ch + j * 8) =
+          *reinterpret_cast<const u32x4_t *>(img + lds_off<TOWER_F>(row, j));
+    }
+  }
+  // value: reduce the lane partials over the block (ring slot 0 is free now), tanh, store
+  {
+    float *red = reinterpret_cast<float *>(ring);
+    for (int off = 32; off >= 1; off >>= 1) { vsum0 += __shfl_xor(vsum0, off); vsum1 += __shfl_xor(vsum1, off); }
+    if (lane == 0) { red[wave * 2] = vsum0; red[wave * 2 + 1] = vsum1; }
+    __syncthreads();
+    if (tid < g.gpb && game0 + tid < g.n_games) {
+      float sacc = g.vb;
+      for (int w = 0; w < 8; ++w) sacc += red[w * 2 + tid];
+      g.value[game0 + tid] = tanhf(sacc);
+    }
+  }
+}
+
+// ================================================================================================
+// k_fc256: the policy Linear (net.py:25: A -> A, 553 M weights at 14x14 = 1.1 GB in 16 bit) as a
+// weight-streaming GEMM for M = 256 rows.  HBM-bound: every weight byte is used once per forward.
+//   * W is stored by the exporter in MFMA FRAGMENT ORDER  [kstep16][n_tile32][lane 64][8 elems]
+//     (k-step major: all waves advance through K together, so what the chip reads at any moment is one
+//     contiguous region spread over every HBM channel instead of 1472 streams 1.4 MB apart):
+//     one v_mfma_f32_32x32x16 B-operand of a wave is one contiguous, perfectly coalesced 1-KiB read
+//     that goes straight from HBM into VGPRs -- the weights never touch LDS and are never shared
+//     between waves (each wave owns 32 output columns for all 256 rows).
+//   * Each wave keeps 4 stages (8 k-steps, 8 KiB) of its weight stream in flight.
+//   * Only the activations X[256][K] (12 MB, L2/MALL resident, re-read by every block) go through
+//     LDS (16 kB double buffer, swizzled), shared by the block's 4 waves.
+//   * grid = (Np/128) x SPLITK; partial sums [SPLITK][256][Np] f32 are combined with the bias in a
+//     fixed order by k_fc_reduce (deterministic, no atomics).
+// ================================================================================================
+struct FcArgs {
+  const uint16_t *X;      // [Mpad][Kp]
+  const uint16_t *Wf;     // fragment order
+  float *part;            // [splitk][Mtot][Np]
+  int Kp, Np, ksteps, splitk, Mtot;
+};
+
+template <int DT>
+__global__ void __launch_bounds__(256, 2) k_fc256(FcArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned char As[2][256 * 32 * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntile = blockIdx.x * 4 + wave;
+  const int KS = g.ksteps / g.splitk;             // k-steps (of 16) handled by this block; multiple of 8
+  const int ks0 = blockIdx.y * KS;
+  const int S = KS / 2;                           // stages of BK = 32
+  const long wstride = (long)(g.Np / 32) * 64;    // u32x4 units between consecutive k-steps
+  const u32x4_t *wsrc = reinterpret_cast<const u32x4_t *>(g.Wf) + ((long)ks0 * (g.Np / 32) + ntile) * 64 + lane;
+  const long mrow0 = (long)blockIdx.z * 256;
+
+  f32x16_t acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  u32x4_t wq[4][2];       // weight fragments of stages s .. s+3 (ring, statically indexed by unrolling)
+  u32x4_t ra[2][4];       // activation chunks two stages ahead (slot = stage parity)
+  // NOTE: no conditionals around memory operations inside the steady-state loop -- a branch makes
+  // hipcc fall back to s_waitcnt vmcnt(0) at the join, which would serialise every stage on the full
+  // memory latency.  The host guarantees S % 4 == 0 and S >= 8; the last four stages run in a
+  // load-free epilogue copy of the step.
+#define FPC_ALOAD(SLOT_, S_)                                                                         \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+    const int c_ = tid + 256 * i;                                                                    \
+    ra[SLOT_][i] = *reinterpret_cast<const u32x4_t *>(g.X + (mrow0 + (c_ >> 2)) * g.Kp + (long)(ks0 + 2 * (S_)) * 16 + (c_ & 3) * 8); \
+  }
+#define FPC_ASTORE(SLOT_, BUF_)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+    const int c_ = tid + 256 * i;                                                                    \
+    *reinterpret_cast<u32x4_t *>(As[BUF_] + lds_off<32>(c_ >> 2, c_ & 3)) = ra[SLOT_][i];            \
+  }
+#define FPC_WLOADQ(SLOT_, S_)                                                                        \
+  { wq[SLOT_][0] = wsrc[(long)(2 * (S_)) * wstride]; wq[SLOT_][1] = wsrc[(long)(2 * (S_) + 1) * wstride]; }
+  // 16 MFMAs of one stage; the 16 activation fragments are read from LDS four at a time, one group
+  // ahead of the MFMAs that consume them (order pinned: hipcc otherwise serialises read->wait->mfma)
+#define FPC_RD4(DST, KS_, T0_)                                                                       \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                      \
+    DST[q] = *reinterpret_cast<const u32x4_t *>(ab_ + lds_off<32>(((T0_) + q) * 32 + (lane & 31), (KS_) * 2 + (lane >> 5)));
+#define FPC_MM4(SRC, W_, T0_)                                                                        \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) acc[(T0_) + q] = E16<DT>::mfma(SRC[q], W_, acc[(T0_) + q]);
+#define FPC_FCMMA(S_, SLOT_)                                                                         \
+  {                                                                                                  \
+    const unsigned char *ab_ = As[(S_) & 1];                                                         \
+    u32x4_t fp[4], fq[4];                                                                            \
+    FPC_RD4(fp, 0, 0); FPC_RD4(fq, 0, 4); __builtin_amdgcn_sched_barrier(0);                         \
+    FPC_MM4(fp, wq[SLOT_][0], 0); __builtin_amdgcn_sched_barrier(0); FPC_RD4(fp, 1, 0); __builtin_amdgcn_sched_barrier(0); \
+    FPC_MM4(fq, wq[SLOT_][0], 4); __builtin_amdgcn_sched_barrier(0); FPC_RD4(fq, 1, 4); __builtin_amdgcn_sched_barrier(0); \
+    FPC_MM4(fp, wq[SLOT_][1], 0); __builtin_amdgcn_sched_barrier(0);                                 \
+    FPC_MM4(fq, wq[SLOT_][1], 4); __builtin_amdgcn_sched_barrier(0);                                 \
+  }
+
+  FPC_WLOADQ(0, 0); FPC_WLOADQ(1, 1); FPC_WLOADQ(2, 2); FPC_WLOADQ(3, 3);
+  FPC_ALOAD(0, 0);
+  FPC_ASTORE(0, 0);
+  FPC_ALOAD(1, 1); FPC_ALOAD(0, 2);
+  __syncthreads();
+  // stage s: MFMAs on As[s&1]; publish stage s+1 (slot (s+1)&1) to the other LDS buffer, then refill
+  // that slot with stage s+3 and the weight slot s%4 with stage s+4
+#define FPC_FCSTEP(S_, WSLOT_, ANEXT_)                                                               \
+  {                                                                                                  \
+    FPC_FCMMA(S_, WSLOT_);                                                                           \
+    if (FPC_FC_VARIANT != 1) FPC_WLOADQ(WSLOT_, (S_) + 4);                                           \
+    if (FPC_FC_VARIANT != 2) { FPC_ASTORE(ANEXT_, ((S_) + 1) & 1);                                   \
+    FPC_ALOAD(ANEXT_, (S_) + 3); }                                                                   \
+    __syncthreads();                                                                                 \
+  }
+  int s = 0;
+  for (; s + 4 < S; s += 4) {
+    FPC_FCSTEP(s, 0, 1); FPC_FCSTEP(s + 1, 1, 0); FPC_FCSTEP(s + 2, 2, 1); FPC_FCSTEP(s + 3, 3, 0);
+  }
+  // last four stages: nothing left to fetch (slots already hold stages s+1, s+2; s+3 was requested)
+  FPC_FCMMA(s, 0); FPC_ASTORE(1, (s + 1) & 1); FPC_ALOAD(1, s + 3); __syncthreads();
+  FPC_FCMMA(s + 1, 1); FPC_ASTORE(0, (s + 2) & 1); __syncthreads();
+  FPC_FCMMA(s + 2, 2); FPC_ASTORE(1, (s + 3) & 1); __syncthreads();
+  FPC_FCMMA(s + 3, 3);
+#undef FPC_FCSTEP
+#undef FPC_FCMMA
+#undef FPC_RD4
+#undef FPC_MM4
+#undef FPC_ALOAD
+#undef FPC_ASTORE
+#undef FPC_WLOADQ
+  float *out = g.part + ((long)blockIdx.y * g.Mtot + mrow0) * g.Np;
+  const int n = ntile * 32 + (lane & 31);
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      out[(long)m * g.Np + n] = acc[t][r];
+    }
+}
+
+// logits[m][n] = bias[n] + part[0][m][n] + part[1][m][n] + ...   (fixed order)
+__global__ void __launch_bounds__(256) k_fc_reduce(const float *part, const float *bias, int splitk, int Mtot, int Np, int A, int n_rows,
+                                                   float *logits) {
+  const int q = blockIdx.x * 256 + threadIdx.x;         // float4 index within a row
+  const int m = blockIdx.y;
+  if (m >= n_rows || q * 4 >= A) return;
+  float4 v = *reinterpret_cast<const float4 *>(bias + q * 4);
+  for (int k = 0; k < splitk; ++k) {
+    const float4 p = *reinterpret_cast<const float4 *>(part + ((long)k * Mtot + m) * Np + q * 4);
+    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+  }
+  *reinterpret_cast<float4 *>(logits + (long)m * A + q * 4) = v;
+}
+
 // value head tail: Flatten + Linear(24*R*R -> 1) + Tanh (net.py:33-34) on the value conv output
 template <int DT>
 __global__ void __launch_bounds__(64) k_value_tail(const uint16_t *Y, const float *w, float bias, int P, int R, int PP,
@@ -377,13 +814,13 @@ __global__ void __launch_bounds__(64) k_nchw_to_grid(const float *x, int n, int 
 
 // ------------------------------------------------------------------------------------------------
 // weight blob (written by alphazero-4-player-chess_amd/weights.py):
-//   header  : char magic[4]="FPCW"; int32 version=1, R, F, nblocks, dtype, A_ch, Np, Kp; pad to 64 B
+//   header  : char magic[4]="FPCW"; int32 version=2, R, F, nblocks, dtype, A_ch, Np, Kp; pad to 64 B
 //   sections, each 64-B aligned, in this order:
 //     stem   w16[9][Fp][32]     b f32[Fp]          (Fp = F rounded up to 128)
 //     block i: c1 w16[9][Fp][F] b f32[Fp] ; c2 w16[9][Fp][F] b f32[Fp]
 //     policy conv w16[9][128][F] b f32[128]
 //     value  conv w16[9][128][F] b f32[128]  (both heads: Cout zero-padded to the 128-wide tile)
-//     policy fc   w16[Np][Kp]    b f32[Np]
+//     policy fc   w16 in MFMA fragment order [Kp/16][Np/32][64 lanes][8] (lane = 32*(k/8%2) + n%32)   b f32[Np]
 //     value  fc   w f32[R*R][32] b f32[1]
 // ------------------------------------------------------------------------------------------------
 struct BlobHeader {
@@ -415,6 +852,10 @@ struct NN {
   std::vector<ConvW> c1, c2;
   uint16_t *fcw = nullptr;
   float *fcb = nullptr, *vw = nullptr;
+  float *fc_part = nullptr;      // [FC_SPLITK][Gpad][Np] partial sums of k_fc256
+  uint16_t *towerW = nullptr;    // [2*nblocks][9][128][128] contiguous copy for k_tower (F == 128)
+  float *towerB = nullptr;
+  bool use_tower = false;
   float vb = 0.f;
   bool attr_set[2] = {false, false};
 
@@ -432,7 +873,7 @@ struct NN {
     dc = c; Gmax = max_games; dtype = nn_dtype ? 1 : 0; stream = s;
     P = c.R + 2; PP = P * P;
     Mrows = ((max_games * PP + CONV_BM - 1) / CONV_BM) * CONV_BM;
-    Gpad = ((max_games + GEMM_BM - 1) / GEMM_BM) * GEMM_BM;
+    Gpad = ((max_games + 255) / 256) * 256;
     return 0;
   }
   void destroy() {
@@ -449,7 +890,7 @@ struct NN {
     if (nbytes < sizeof(BlobHeader)) { *err = "weight blob too small"; return FPC_EWEIGHTS; }
     BlobHeader h;
     memcpy(&h, blob, sizeof(h));
-    if (memcmp(h.magic, "FPCW", 4) || h.version != 1) { *err = "bad weight blob magic/version"; return FPC_EWEIGHTS; }
+    if (memcmp(h.magic, "FPCW", 4) || h.version != 2) { *err = "bad weight blob magic/version"; return FPC_EWEIGHTS; }
     if (h.R != dc.R || h.A_ch != dc.A_ch) { *err = "weight blob is for a different board size"; return FPC_EWEIGHTS; }
     if (h.dtype != dtype) { *err = "weight blob dtype differs from engine nn_dtype"; return FPC_EWEIGHTS; }
     if (h.F % 64 || h.F < 64 || h.F > 512 || h.nblocks < 0 || h.Np % GEMM_BN || h.Kp % 64 || h.Np < dc.A || h.Kp < dc.A) {
@@ -493,8 +934,26 @@ struct NN {
     for (auto &a : act) if ((rc = dmalloc(&a, rows * F, err))) return rc;
     if ((rc = dmalloc(&yv, rows * 32, err))) return rc;
     if ((rc = dmalloc(&xfc, (size_t)Gpad * Kp, err))) return rc;
+    if ((rc = dmalloc(&fc_part, (size_t)FC_SPLITK * Gpad * Np, err))) return rc;
     if ((rc = dmalloc(&d_logits, (size_t)Gmax * dc.A, err))) return rc;
     if ((rc = dmalloc(&d_value, (size_t)Gmax, err))) return rc;
+    use_tower = false;
+    if (F == TOWER_F && PP <= 256 && !getenv("FPC_NO_TOWER")) {
+      const size_t per = (size_t)9 * 128 * 128;
+      if ((rc = dmalloc(&towerW, per * (2 * nblocks + 2), err)) || (rc = dmalloc(&towerB, (size_t)128 * (2 * nblocks + 2), err))) return rc;
+      for (int i = 0; i < nblocks; ++i) {
+        (void)hipMemcpy(towerW + per * (2 * i), c1[i].w, per * 2, hipMemcpyDeviceToDevice);
+        (void)hipMemcpy(towerW + per * (2 * i + 1), c2[i].w, per * 2, hipMemcpyDeviceToDevice);
+        (void)hipMemcpy(towerB + 128 * (2 * i), c1[i].b, 128 * 4, hipMemcpyDeviceToDevice);
+        (void)hipMemcpy(towerB + 128 * (2 * i + 1), c2[i].b, 128 * 4, hipMemcpyDeviceToDevice);
+      }
+      // heads ride the same weight stream: layer L = value conv, layer L+1 = policy conv
+      (void)hipMemcpy(towerW + per * (2 * nblocks), vconv.w, per * 2, hipMemcpyDeviceToDevice);
+      (void)hipMemcpy(towerW + per * (2 * nblocks + 1), pconv.w, per * 2, hipMemcpyDeviceToDevice);
+      (void)hipMemcpy(towerB + 128 * (2 * nblocks), vconv.b, 128 * 4, hipMemcpyDeviceToDevice);
+      (void)hipMemcpy(towerB + 128 * (2 * nblocks + 1), pconv.b, 128 * 4, hipMemcpyDeviceToDevice);
+      use_tower = true;
+    }
     loaded = true;
     return 0;
   }
@@ -557,24 +1016,40 @@ struct NN {
       g.P = P; g.R = dc.R; g.PP = PP; g.n_valid = n_valid; g.m_valid = n; g.mode = mode;
       return launch_conv<DT>(g, M, err);
     };
-    if ((rc = conv(stem, in16, 32, nullptr, act[0], F, F, 0))) return rc;
     int cur = 0;
-    for (int i = 0; i < nblocks; ++i) {
+    if (use_tower) {
+      TowerArgs t{};
+      t.in16 = in16 + (size_t)guard * 32; t.Wstem = stem.w; t.bstem = stem.b; t.Wt = towerW; t.bt = towerB;
+      t.out = act[0] + (size_t)guard * F; t.L = 2 * nblocks; t.P = P; t.R = dc.R; t.PP = PP; t.gpb = 256 / PP; t.n_games = n;
+      t.heads = 1; t.xfc = xfc; t.vw = vw; t.value = value_out; t.vb = vb; t.Kp = Kp; t.A_ch = dc.A_ch;
+      static bool attr = false;
+      if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, TOWER_LDS); attr = true; }
+      hipLaunchKernelGGL((k_tower<DT>), dim3((n + t.gpb - 1) / t.gpb), dim3(TOWER_THREADS), TOWER_LDS, stream, t);
+      const hipError_t le = hipGetLastError();
+      if (le != hipSuccess) { *err = std::string("k_tower launch failed: ") + hipGetErrorString(le); return FPC_ENODEVICE; }
+    } else if ((rc = conv(stem, in16, 32, nullptr, act[0], F, F, 0))) return rc;
+    for (int i = 0; i < nblocks && !use_tower; ++i) {
       const int t1 = (cur + 1) % 3, t2 = (cur + 2) % 3;
       if ((rc = conv(c1[i], act[cur], F, nullptr, act[t1], F, F, 0))) return rc;
       if ((rc = conv(c2[i], act[t1], F, act[cur], act[t2], F, F, 0))) return rc;
       cur = t2;
     }
-    if ((rc = conv(pconv, act[cur], F, nullptr, xfc, Kp, dc.A_ch, 1))) return rc;
-    if ((rc = conv(vconv, act[cur], F, nullptr, yv, 32, 24, 0))) return rc;
-    {
-      GemmArgs g{};
-      g.A = xfc; g.B = fcw; g.bias = fcb; g.Res = nullptr; g.out = logits_out;
-      g.M = ((n + GEMM_BM - 1) / GEMM_BM) * GEMM_BM; g.N_pad = Np; g.K_tap = Kp; g.ntaps = 1; g.lda = Kp; g.ldo = dc.A;
-      g.P = P; g.R = dc.R; g.PP = PP; g.n_valid = dc.A; g.m_valid = n; g.mode = 2;
-      if ((rc = launch_gemm<DT>(g, 64, err))) return rc;
+    if (!use_tower) {
+      if ((rc = conv(pconv, act[cur], F, nullptr, xfc, Kp, dc.A_ch, 1))) return rc;
+      if ((rc = conv(vconv, act[cur], F, nullptr, yv, 32, 24, 0))) return rc;
     }
-    hipLaunchKernelGGL((k_value_tail<DT>), dim3(n), dim3(64), 0, stream, (const uint16_t *)(yv + (size_t)guard * 32),
+    {
+      FcArgs f{};
+      f.X = xfc; f.Wf = fcw; f.part = fc_part; f.Kp = Kp; f.Np = Np; f.ksteps = Kp / 16; f.splitk = FC_SPLITK; f.Mtot = Gpad;
+      const int mtiles = (n + 255) / 256;
+      if ((Kp / 16 / FC_SPLITK / 2) % 4 != 0 || Kp / 16 / FC_SPLITK / 2 < 8) { *err = "policy Linear K does not fit the FC pipeline (K/64 must be a multiple of 4)"; return FPC_EWEIGHTS; }
+      hipLaunchKernelGGL((k_fc256<DT>), dim3(Np / 128, FC_SPLITK, mtiles), dim3(256), 0, stream, f);
+      hipLaunchKernelGGL(k_fc_reduce, dim3((dc.A / 4 + 255) / 256, n), dim3(256), 0, stream, (const float *)fc_part, (const float *)fcb,
+                         FC_SPLITK, Gpad, Np, dc.A, n, logits_out);
+      const hipError_t le = hipGetLastError();
+      if (le != hipSuccess) { *err = std::string("k_fc256 launch failed: ") + hipGetErrorString(le); return FPC_ENODEVICE; }
+    }
+    if (!use_tower) hipLaunchKernelGGL((k_value_tail<DT>), dim3(n), dim3(64), 0, stream, (const uint16_t *)(yv + (size_t)guard * 32),
                        (const float *)vw, vb, P, dc.R, PP, n, value_out);
     if (hipGetLastError() != hipSuccess) { *err = "k_value_tail launch failed"; return FPC_ENODEVICE; }
     return 0;

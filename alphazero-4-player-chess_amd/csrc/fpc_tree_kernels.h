@@ -44,6 +44,7 @@ struct Tree {
   // per game scalars
   int *nnodes, *nboards, *alive, *sims_done, *err;
   int *leaf_node;    // leaf chosen this step (-1: none)
+  int *leaf_slot;    // board-pool slot of that leaf's state (-1: none) -- what k_encode reads
   int *leaf_turn;
   int *nlegal;
   uint16_t *legal;   // [G][FPC_MAX_MOVES] ascending unique flat indices of the leaf's legal moves
@@ -658,7 +659,7 @@ __global__ void __launch_bounds__(64) k_search_init(Tree t, int G, const fpc_boa
   t.N[nb] = 1; t.W[nb] = 0.0; t.P[nb] = 0.f; t.mv[nb] = 0xffff; t.parent[nb] = -1; t.child0[nb] = -1; t.nch[nb] = 0;
   t.bslot[nb] = 0;
   t.nnodes[g] = 1; t.nboards[g] = 1; t.alive[g] = 1; t.sims_done[g] = 0; t.err[g] = 0;
-  t.leaf_node[g] = -1; t.leaf_turn[g] = 0; t.nlegal[g] = 0;
+  t.leaf_node[g] = -1; t.leaf_slot[g] = -1; t.leaf_turn[g] = 0; t.nlegal[g] = 0;
 }
 
 // root read-back (alphazero.py:104-110 reads GetChildren / GetFlatIndex / GetVisitCount)
@@ -701,7 +702,7 @@ __global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double C
   if (g >= G) return;
   const int lane = lane_id();
   if (!t.alive[g]) {                        // root already removed from the search (Q5)
-    if (lane == 0) t.leaf_node[g] = -1;
+    if (lane == 0) { t.leaf_node[g] = -1; t.leaf_slot[g] = -1; }
     return;
   }
   const size_t nb = (size_t)g * t.node_cap;
@@ -743,7 +744,7 @@ __global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double C
     n = c0 + besti;
   }
   if (fail) {                                // node.cpp:72-75 throws
-    if (lane == 0) { t.err[g] |= ERR_SELECT; t.alive[g] = 0; t.leaf_node[g] = -1; }
+    if (lane == 0) { t.err[g] |= ERR_SELECT; t.alive[g] = 0; t.leaf_node[g] = -1; t.leaf_slot[g] = -1; }
     return;
   }
   // ---- leaf state: the reference copies + MakeMoves a Board for every child at expansion time
@@ -781,21 +782,14 @@ __global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double C
       t.sims_done[g] += 1;
       t.alive[g] = 0;
       t.leaf_node[g] = -1;
+      t.leaf_slot[g] = -1;
     }
     return;
   }
   const int nl = s.nlegal;
   uint16_t *lg = t.legal + (size_t)g * FPC_MAX_MOVES;
   for (int k = lane; k < nl; k += 64) lg[k] = s.lsorted[k];
-  if (lane == 0) { t.leaf_node[g] = n; t.leaf_turn[g] = s.b.turn; t.nlegal[g] = nl; }
-}
-
-// leaf board slot per game for k_encode (-1 when the game has no leaf this step)
-__global__ void __launch_bounds__(64) k_leaf_slots(Tree t, int G, int *slot_out) {
-  const int g = blockIdx.x * 64 + threadIdx.x;
-  if (g >= G) return;
-  const int n = t.leaf_node[g];
-  slot_out[g] = n < 0 ? -1 : t.bslot[(size_t)g * t.node_cap + n];
+  if (lane == 0) { t.leaf_node[g] = n; t.leaf_slot[g] = slot; t.leaf_turn[g] = s.b.turn; t.nlegal[g] = nl; }
 }
 
 // ================================================================================================

@@ -67,8 +67,12 @@ def export_weights(model, dtype=0):
     fwp = torch.zeros(Np, Kp, dtype=t16)
     fwp[:A, :A] = fw.to(t16)
     del fw
-    secs.append(fwp.view(torch.int16).numpy().tobytes())
+    # MFMA fragment order (csrc/fpc_nn.h k_fc256): [kstep16][n_tile32][lane = 32*h + r][8],
+    # element (ks, nt, h, r, e) = W'[nt*32 + r][ks*16 + h*8 + e]
+    wf = fwp.view(Np // 32, 32, Kp // 16, 2, 8).permute(2, 0, 3, 1, 4).contiguous()
     del fwp
+    secs.append(wf.view(torch.int16).numpy().tobytes())
+    del wf
     fb = np.zeros(Np, np.float32)
     fb[:A] = fc.bias.detach().float().numpy()
     secs.append(fb.tobytes())
@@ -77,7 +81,7 @@ def export_weights(model, dtype=0):
     vw[:, :24] = vfc.weight.detach().float().view(24, RR).t()
     secs.append(vw.numpy().astype(np.float32).tobytes())
     secs.append(struct.pack("<f", float(vfc.bias.detach().float().item())))
-    out = bytearray(struct.pack("<4s8i28x", b"FPCW", 1, R, F, nblocks, dtype, A_ch, Np, Kp))
+    out = bytearray(struct.pack("<4s8i28x", b"FPCW", 2, R, F, nblocks, dtype, A_ch, Np, Kp))
     assert len(out) == 64
     for s in secs:
         out += b"\0" * ((-len(out)) % 64)

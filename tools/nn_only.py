@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Runs only the network forward (fpc_nn_forward) a few times: a short target for rocprofv3 --pmc."""
+import os, sys
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(HERE, "alphazero-4-player-chess_amd"), HERE]
+import numpy as np, torch
+import fpc_ffi, net, weights
+if os.environ.get('FPC_VARIANT_LIB'):
+    fpc_ffi.LIB_PATH = os.environ['FPC_VARIANT_LIB']   # timing experiments only (tools/var/*.so)
+from bench import Spec
+R, G, iters = 14, 256, int(sys.argv[1]) if len(sys.argv) > 1 else 5
+torch.manual_seed(0)
+m = net.ResNet(Spec(R), 10, 128, "cpu").eval()
+eng = fpc_ffi.Engine(R, 3, max_games=G, max_sims=8)
+eng.load_weights(weights.export_weights(m, 0))
+x = (torch.rand(G, 24, R, R) < 0.1).float().cuda()
+lg = torch.empty(G, eng.A, device="cuda"); va = torch.empty(G, device="cuda")
+torch.cuda.synchronize()
+for _ in range(iters):
+    eng.nn_forward(x.data_ptr(), G, lg.data_ptr(), va.data_ptr())
+print("done", float(lg.abs().mean()))

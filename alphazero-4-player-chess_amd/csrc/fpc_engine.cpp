@@ -441,7 +441,7 @@ int fpc_search_expand(fpc_engine *e, const float *logits_dev, const float *value
   if (!e || !e->searching) return fail(e, FPC_ESTATE, "fpc_search_begin has not been called");
   if (!logits_dev || !value_dev) return fail(e, FPC_EINVAL, "null logits/value");
   mark(e, 2);
-  FPC_LAUNCH(k_expand, e->G, 64, e->stream, e->dc, e->t, e->G, logits_dev, value_dev);
+  FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, logits_dev, value_dev);
   HIPCHK(e, hipGetLastError());
   mark(e, 3);
   e->stats.launches_expand++;
@@ -464,7 +464,7 @@ int fpc_search_run(fpc_engine *e, int sims) {
     int r = e->nn.forward(e->G, &e->err);
     if (r) return r;
     mark(e, 2);
-    FPC_LAUNCH(k_expand, e->G, 64, e->stream, e->dc, e->t, e->G, (const float *)e->nn.logits(), (const float *)e->nn.value());
+    FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (const float *)e->nn.logits(), (const float *)e->nn.value());
     mark(e, 3);
     e->stats.launches_select++; e->stats.launches_nn++; e->stats.launches_expand++;
   }

@@ -63,7 +63,7 @@ struct GemmArgs {
 };
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128;
-constexpr int FC_SPLITK = 2;
+constexpr int FC_SPLITK = 4;   // 736 blocks at 14x14: fine-grained enough for the dispatcher to balance 256 CUs
 
 // byte offset of 16-B chunk j of tile row `row` (BK elements per row), XOR-swizzled so that the
 // 16-lane groups of a ds_read_b128 touch 16 distinct 16-B slots of the 256-B bank row

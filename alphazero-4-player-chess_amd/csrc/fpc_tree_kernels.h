@@ -831,15 +831,18 @@ __device__ __forceinline__ float fdiv_rn(float a, float b) {
 //   p = softmax(logits) over all A entries;  policy_abs[pl][r][c] = p[pl][rot90 by -turn0]  (Q6);
 //   prior_j = p_src(j) / sum_legal p  for the ascending legal list; exact zeros get no child;
 //   BackpropagateNodes(value) first (Q4), then children appended with N=1 (Q1), W=0.
-// Summation orders are part of the numeric spec: S = lane partials over float4 groups
-// (group q belongs to lane q%64, ascending) + xor butterfly; the legal mass is a sequential
-// ascending f32 sum.
+// Summation orders are part of the numeric spec: S = thread partials over float4 groups
+// (group q belongs to thread q%256, ascending) + per-wave xor butterfly + the 4 wave sums in wave
+// order; the legal mass is a sequential ascending f32 sum.
 // ================================================================================================
-__global__ void __launch_bounds__(64) k_expand(DevCfg c, Tree t, int G, const float *logits, const float *value) {
+constexpr int EXPAND_THREADS = 256;   // 4 waves stream the logits row; wave 0 then finishes alone
+__global__ void __launch_bounds__(EXPAND_THREADS) k_expand(DevCfg c, Tree t, int G, const float *logits, const float *value) {
   __shared__ WaveLds s;
+  __shared__ float red_f[4];
+  __shared__ int red_i[4];
   const int g = blockIdx.x;
   if (g >= G) return;
-  const int lane = lane_id();
+  const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
   const int turn0 = first_leaf_turn(t.leaf_node, t.leaf_turn, G);
   const int n = t.leaf_node[g];
   if (n < 0) return;
@@ -849,16 +852,23 @@ __global__ void __launch_bounds__(64) k_expand(DevCfg c, Tree t, int G, const fl
   // pass 1: max
   float m = -__builtin_inff();
   bool nan = false;
-  for (int q = lane; q < ngroups; q += 64) {
+  for (int q = tid; q < ngroups; q += EXPAND_THREADS) {
     const float4 v = *reinterpret_cast<const float4 *>(lg + 4 * q);
     nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
     m = v.x > m ? v.x : m; m = v.y > m ? v.y : m; m = v.z > m ? v.z : m; m = v.w > m ? v.w : m;
   }
   for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(m, off); m = o > m ? o : m; }
-  nan = __ballot(nan) != 0ull;
-  // pass 2: S
+  const bool wnan = __ballot(nan) != 0ull;
+  if (lane == 0) { red_f[wave] = m; red_i[wave] = wnan ? 1 : 0; }
+  __syncthreads();
+  m = red_f[0];
+  m = red_f[1] > m ? red_f[1] : m; m = red_f[2] > m ? red_f[2] : m; m = red_f[3] > m ? red_f[3] : m;
+  nan = (red_i[0] | red_i[1] | red_i[2] | red_i[3]) != 0;
+  __syncthreads();
+  // pass 2: S.  Thread t owns the float4 groups q with q % 256 == t (ascending), each wave folds its
+  // 64 partials with the xor butterfly, and the four wave sums are added in wave order.
   float part = 0.f;
-  for (int q = lane; q < ngroups; q += 64) {
+  for (int q = tid; q < ngroups; q += EXPAND_THREADS) {
     const float4 v = *reinterpret_cast<const float4 *>(lg + 4 * q);
     part = part + fpc_expf(v.x - m);
     part = part + fpc_expf(v.y - m);
@@ -866,6 +876,10 @@ __global__ void __launch_bounds__(64) k_expand(DevCfg c, Tree t, int G, const fl
     part = part + fpc_expf(v.w - m);
   }
   for (int off = 32; off >= 1; off >>= 1) part = part + __shfl_xor(part, off);
+  if (lane == 0) red_f[wave] = part;
+  __syncthreads();
+  if (wave != 0) return;                     // the rest is one wave's work (uniform exit of waves 1-3)
+  part = ((red_f[0] + red_f[1]) + red_f[2]) + red_f[3];
   const float inv = fdiv_rn(1.0f, part);
   // legal priors
   const int nl = t.nlegal[g];

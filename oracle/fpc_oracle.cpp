@@ -629,23 +629,25 @@ float orc_expf(float x) {
 }
 
 // mcts.py:67-76.  Numeric spec (DESIGN.md "policy head-to-prior arithmetic"):
-//   m = max logits; e_i = fpc_expf(l_i - m); S = wave-ordered sum (lane l owns the float4 groups
-//   g with g % 64 == l, added in ascending order; then xor-butterfly 32,16,..,1);
+//   m = max logits; e_i = fpc_expf(l_i - m); S = thread-ordered sum (thread t of 256 owns the float4
+//   groups g with g % 256 == t, added in ascending order; xor-butterfly 32,16,..,1 inside each of
+//   the four 64-lane waves; then ((w0+w1)+w2)+w3);
 //   p_i = e_i * (1/S); priors = p_src / (sequential ascending sum of p over the legal set).
 int orc_policy_priors(const float *logits, int R, int turn0, const int *legal_flat, int n_legal, float *priors) {
   int A = orc_action_size(R), RR = R * R;
   float m = -std::numeric_limits<float>::infinity();
   bool has_nan = false;
   for (int i = 0; i < A; ++i) { if (logits[i] != logits[i]) has_nan = true; if (logits[i] > m) m = logits[i]; }
-  float part[64];
-  for (int l = 0; l < 64; ++l) part[l] = 0.f;
-  for (int i = 0; i < A; ++i) part[(i / 4) % 64] = part[(i / 4) % 64] + orc_expf(logits[i] - m);
-  for (int off = 32; off >= 1; off >>= 1) {
-    float nxt[64];
-    for (int l = 0; l < 64; ++l) nxt[l] = part[l] + part[l ^ off];
-    memcpy(part, nxt, sizeof(part));
-  }
-  float S = part[0];
+  float part[256];
+  for (int l = 0; l < 256; ++l) part[l] = 0.f;
+  for (int i = 0; i < A; ++i) part[(i / 4) % 256] = part[(i / 4) % 256] + orc_expf(logits[i] - m);
+  for (int w = 0; w < 4; ++w)
+    for (int off = 32; off >= 1; off >>= 1) {
+      float nxt[64];
+      for (int l = 0; l < 64; ++l) nxt[l] = part[w * 64 + l] + part[w * 64 + (l ^ off)];
+      memcpy(part + w * 64, nxt, sizeof(nxt));
+    }
+  float S = ((part[0] + part[64]) + part[128]) + part[192];
   float inv = 1.0f / S;
   float T = 0.f;
   for (int j = 0; j < n_legal; ++j) {

@@ -3,8 +3,6 @@
 
 namespace wemu {
 
-static int g_tag[WAVE];
-
 State &st() {
   static State s;
   return s;
@@ -14,27 +12,33 @@ static void trampoline() {
   State &s = st();
   s.body();
   s.done[s.cur] = true;
+  s.block_live--;
+  s.wave_live[s.cur / WAVE]--;
   swapcontext(&s.lane_ctx[s.cur], &s.main_ctx);
 }
 
-void barrier() {
+void yield() {
   State &s = st();
   swapcontext(&s.lane_ctx[s.cur], &s.main_ctx);
 }
 
 void run_grid(int grid, int block, const std::function<void()> &body) {
-  if (block != WAVE) {
-    fprintf(stderr, "wave_emul: block size must be 64, got %d\n", block);
+  if (block <= 0 || block > MAX_THREADS || block % WAVE) {
+    fprintf(stderr, "wave_emul: block size must be a multiple of 64 up to %d, got %d\n", MAX_THREADS, block);
     abort();
   }
   State &s = st();
   constexpr size_t STK = 256 * 1024;
-  if (!s.stacks[0])
-    for (int l = 0; l < WAVE; ++l) s.stacks[l] = (char *)malloc(STK);
+  for (int l = 0; l < block; ++l)
+    if (!s.stacks[l]) s.stacks[l] = (char *)malloc(STK);
   s.body = body;
+  s.nthreads = block;
   for (int b = 0; b < grid; ++b) {
     s.block_idx.x = (unsigned)b;
-    for (int l = 0; l < WAVE; ++l) {
+    s.block_bar = Bar();
+    s.block_live = block;
+    for (int w = 0; w < block / WAVE; ++w) { s.wave_bar[w] = Bar(); s.wave_live[w] = WAVE; }
+    for (int l = 0; l < block; ++l) {
       getcontext(&s.lane_ctx[l]);
       s.lane_ctx[l].uc_stack.ss_sp = s.stacks[l];
       s.lane_ctx[l].uc_stack.ss_size = STK;
@@ -44,7 +48,7 @@ void run_grid(int grid, int block, const std::function<void()> &body) {
     }
     for (;;) {
       bool any = false;
-      for (int l = 0; l < WAVE; ++l) {
+      for (int l = 0; l < block; ++l) {
         if (s.done[l]) continue;
         any = true;
         s.cur = l;
@@ -53,7 +57,6 @@ void run_grid(int grid, int block, const std::function<void()> &body) {
       if (!any) break;
     }
   }
-  (void)g_tag;
 }
 
 }  // namespace wemu

@@ -3,9 +3,10 @@
 // A lock-step emulator of ONE 64-lane CDNA wavefront per block, so that the CPU test-suite
 // (pytest -m "not gpu", no GPU in the build container) can execute the very same tree-kernel source
 // that hipcc compiles for gfx950 (alphazero-4-player-chess_amd/csrc/fpc_tree_kernels.h).  Each lane
-// is a ucontext fibre; every wave collective (__syncthreads, __ballot, __shfl*) is a rendezvous at
-// which the scheduler switches fibres, which reproduces the SIMT semantics the kernels rely on
-// (uniform control flow around collectives).  Blocks run one after another.
+// is a ucontext fibre; wave collectives (__ballot, __shfl*) rendezvous the 64 fibres of a wave and
+// __syncthreads the whole block (generation barriers that tolerate exited lanes, as the hardware
+// barrier does), which reproduces the SIMT semantics the kernels rely on.  Blocks of up to 16 waves
+// run one after another.
 //
 // This is a model of the HARDWARE, not of the algorithm, and it is never part of the product:
 // libfpc_engine.so is built by hipcc only and has no CPU path.  The emulator build
@@ -37,19 +38,38 @@ struct float4 {
 
 namespace wemu {
 constexpr int WAVE = 64;
+constexpr int MAX_THREADS = 1024;
+struct Bar {
+  int count = 0, gen = 0;
+};
 struct State {
   ucontext_t main_ctx;
-  ucontext_t lane_ctx[WAVE];
-  char *stacks[WAVE];
-  bool done[WAVE];
-  int cur;
+  ucontext_t lane_ctx[MAX_THREADS];
+  char *stacks[MAX_THREADS];
+  bool done[MAX_THREADS];
+  int nthreads;
+  int cur;                       // running fibre == threadIdx.x
   wemu_dim3 block_idx;
-  uint64_t slot[WAVE];
+  uint64_t slot[MAX_THREADS];
+  Bar block_bar, wave_bar[MAX_THREADS / WAVE];
+  int block_live, wave_live[MAX_THREADS / WAVE];
   std::function<void()> body;
 };
 State &st();
-void barrier();
+void yield();
 void run_grid(int grid, int block, const std::function<void()> &body);
+
+// generation barrier over a (possibly shrinking) set of live fibres
+inline void wait(Bar &b, const int &live) {
+  const int my = b.gen;
+  b.count++;
+  while (b.gen == my) {
+    if (b.count >= live) { b.count = 0; b.gen++; break; }
+    yield();
+  }
+}
+inline void block_barrier() { State &s = st(); wait(s.block_bar, s.block_live); }
+inline void wave_barrier() { State &s = st(); wait(s.wave_bar[s.cur / WAVE], s.wave_live[s.cur / WAVE]); }
 
 template <class T>
 inline uint64_t to_bits(T v) {
@@ -64,13 +84,15 @@ inline T from_bits(uint64_t b) {
   memcpy(&v, &b, sizeof(T));
   return v;
 }
+// src: lane index within the caller's wave
 template <class T>
 inline T exchange(T v, int src) {
   State &s = st();
+  const int base = (s.cur / WAVE) * WAVE;
   s.slot[s.cur] = to_bits(v);
-  barrier();
-  const T r = (src >= 0 && src < WAVE) ? from_bits<T>(s.slot[src]) : v;
-  barrier();
+  wave_barrier();
+  const T r = (src >= 0 && src < WAVE && base + src < s.nthreads && !s.done[base + src]) ? from_bits<T>(s.slot[base + src]) : v;
+  wave_barrier();
   return r;
 }
 }  // namespace wemu
@@ -88,25 +110,26 @@ struct wemu_bid_proxy {
 static wemu_tid_proxy threadIdx;
 static wemu_bid_proxy blockIdx;
 
-inline void __syncthreads() { wemu::barrier(); }
+inline void __syncthreads() { wemu::block_barrier(); }
 inline unsigned long long __ballot(bool p) {
   wemu::State &s = wemu::st();
+  const int base = (s.cur / wemu::WAVE) * wemu::WAVE;
   s.slot[s.cur] = p ? 1 : 0;
-  wemu::barrier();
+  wemu::wave_barrier();
   unsigned long long m = 0;
-  for (int i = 0; i < wemu::WAVE; ++i)
-    if (!s.done[i] && s.slot[i]) m |= 1ull << i;
-  wemu::barrier();
+  for (int i = 0; i < wemu::WAVE && base + i < s.nthreads; ++i)
+    if (!s.done[base + i] && s.slot[base + i]) m |= 1ull << i;
+  wemu::wave_barrier();
   return m;
 }
 template <class T>
 inline T __shfl(T v, int lane) { return wemu::exchange(v, lane); }
 template <class T>
-inline T __shfl_xor(T v, int mask) { return wemu::exchange(v, wemu::st().cur ^ mask); }
+inline T __shfl_xor(T v, int mask) { return wemu::exchange(v, (wemu::st().cur % wemu::WAVE) ^ mask); }
 template <class T>
 inline T __shfl_up(T v, int delta) {
-  const int src = wemu::st().cur - delta;
-  return wemu::exchange(v, src >= 0 ? src : wemu::st().cur);
+  const int l = wemu::st().cur % wemu::WAVE;
+  return wemu::exchange(v, l - delta >= 0 ? l - delta : l);
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }

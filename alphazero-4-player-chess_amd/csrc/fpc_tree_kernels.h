@@ -57,13 +57,14 @@ struct __attribute__((aligned(16))) WaveLds {
   uint8_t mto[FPC_MAX_MOVES];
   uint8_t mcap[FPC_MAX_MOVES];
   uint8_t mflag[FPC_MAX_MOVES];        // bit0 legal, bit1 promotion (reference emits 4 variants)
+  uint8_t mpiece[FPC_MAX_MOVES];       // piece-list position of the mover (generation order key)
   uint16_t lflat[FPC_MAX_MOVES];       // flat index of legal moves, reference order
   uint16_t lsorted[FPC_MAX_MOVES];     // ascending
   uint8_t lidx[FPC_MAX_MOVES];         // pseudo-move index of k-th legal move
   float pri[FPC_MAX_MOVES];
   uint16_t poff[FPC_MAX_PL + 1];       // first pseudo-move of each piece-list entry
-  uint8_t l0[FPC_MAX_PL];              // own piece list before the GetGameResult reordering
-  uint8_t l1[FPC_MAX_PL];
+  uint8_t l1pos[FPC_MAX_PL];           // own list: position after the GetGameResult reordering
+  uint8_t newlist[3][FPC_MAX_PL];      // reordered lists (own, enemy a, enemy b) before they are copied back
   int M, nlegal, first_legal, result, errbits;
   float scal_f;                        // wave-uniform scalar broadcast slot
 };
@@ -427,6 +428,7 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
     auto put = [&](int to, uint8_t cap, bool promo) {
       if (w < FPC_MAX_MOVES) {
         s->mfrom[w] = (uint8_t)from; s->mto[w] = (uint8_t)to; s->mcap[w] = cap; s->mflag[w] = promo ? 2 : 0;
+        s->mpiece[w] = (uint8_t)p;
       }
       ++w;
     };
@@ -476,38 +478,77 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
   }
   const bool run_legal = do_legal && result == FPC_IN_PROGRESS;
 
-  // ---- piece-list reorderings caused by the reference's make/undo loops (lane 0, closed form:
-  //      every make/undo pair moves the mover's entry, then the captured piece's entry, to the end
-  //      of their lists; engine/board.cpp:1028-1160)
-  if (lane == 0) {
-    if (do_result && player_has_king) {
-      for (int i = 0; i < nown && i < FPC_MAX_PL; ++i) s->l0[i] = b->pl[turn][i];
-      const int upto = nlegal > 0 ? first : M - 1;       // loop returns at the first legal move
-      for (int i = 0; i <= upto; ++i) {
-        list_move_to_end(b->pl[turn], nown, s->mfrom[i]);
-        const uint8_t cap = s->mcap[i];
-        if (present(cap)) list_move_to_end(b->pl[colour_of(cap)], b->plen[colour_of(cap)], s->mto[i]);
-      }
-    }
+  // ---- piece-list reorderings caused by the reference's make/undo loops, in closed form.
+  // Every make/undo pair moves the mover's entry, then the captured piece's entry, to the END of
+  // their lists (engine/board.cpp:977-1014,1028-1160).  GetGameResult does that for moves 0..upto
+  // (it returns at the first legal move), GetLegalMoves afterwards for ALL pseudo-legal moves,
+  // regenerated in the then-current list order.  Net effect:
+  //   own list   : [pieces without moves] [movers GetGameResult did not reach] [movers it reached],
+  //                each group in its previous order;
+  //   enemy lists: never-captured entries keep their order in front, capturable entries follow,
+  //                ordered by the LAST move that captures them (in GetLegalMoves' generation order:
+  //                post-GetGameResult position of the mover, then its per-piece move index).
+  // Lanes 0-15 own the side-to-move entries, lanes 16-31 / 32-47 the entries of the two enemy colours.
+  {
+    const bool phase1 = do_result && player_has_king;
+    const int upto = nlegal > 0 ? first : M - 1;
+    const int pfirst = (phase1 && upto >= 0) ? (int)s->mpiece[upto] : -1;
+    const unsigned long long nmask = nown >= 64 ? ~0ull : ((1ull << nown) - 1ull);
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    const bool own_lane = lane < nown && lane < FPC_MAX_PL;
+    const bool hasmv = own_lane && s->poff[lane + 1] > s->poff[lane];
+    const bool touched1 = hasmv && lane <= pfirst;
+    const unsigned long long T1 = __ballot(touched1), H = __ballot(hasmv);
+    const unsigned long long U1 = nmask & ~T1;
+    // position after GetGameResult's loop (identity when it did not run)
+    const int pos1 = touched1 ? __popcll(U1) + __popcll(T1 & lower) : __popcll(U1 & lower);
+    if (own_lane) s->l1pos[lane] = (uint8_t)(phase1 ? pos1 : lane);
+    int ownpos = lane;
     if (run_legal) {
-      // GetLegalMoves regenerates the pseudo-legal moves from the CURRENT list order: same moves,
-      // grouped per piece in that order.  poff[] is indexed by the position in the list the moves
-      // were generated from (l0 if do_result ran, else the current list).
-      const bool remap = do_result && player_has_king;
-      for (int i = 0; i < nown && i < FPC_MAX_PL; ++i) s->l1[i] = b->pl[turn][i];
-      for (int k = 0; k < nown && k < FPC_MAX_PL; ++k) {
-        const int sq = s->l1[k];
-        int p0 = k;
-        if (remap) { p0 = 0; while (p0 < nown && s->l0[p0] != sq) ++p0; }
-        const int a = s->poff[p0], e = s->poff[p0 + 1];
-        if (e > a) list_move_to_end(b->pl[turn], nown, sq);
-        for (int i = a; i < e; ++i) {
-          const uint8_t cap = s->mcap[i];
-          if (present(cap)) list_move_to_end(b->pl[colour_of(cap)], b->plen[colour_of(cap)], s->mto[i]);
+      const unsigned long long G0 = nmask & ~H, G1 = H & ~T1, G2 = T1;
+      ownpos = !hasmv ? __popcll(G0 & lower)
+                      : (!touched1 ? __popcll(G0) + __popcll(G1 & lower) : __popcll(G0) + __popcll(G1) + __popcll(G2 & lower));
+    } else if (phase1) {
+      ownpos = pos1;
+    }
+    __syncthreads();                          // l1pos visible
+    // enemy entries
+    const int grp = lane >> 4, e = lane & 15;                  // grp 1, 2: enemy colours turn+1, turn+3
+    const int ecol = grp == 1 ? ((turn + 1) & 3) : ((turn + 3) & 3);
+    const bool en_lane = (grp == 1 || grp == 2) && e < b->plen[ecol];
+    const int esq = en_lane ? b->pl[ecol][e] : -1;
+    int lastkey = -1;                                          // -1: not captured by the relevant loop
+    if (run_legal || phase1) {
+      const int lim = run_legal ? M : upto + 1;
+      for (int i = 0; i < lim; ++i) {
+        if (present(s->mcap[i]) && s->mto[i] == esq) {
+          const int pc = s->mpiece[i];
+          const int key = run_legal ? (int)s->l1pos[pc] * 256 + (i - (int)s->poff[pc]) : i;
+          lastkey = key > lastkey ? key : lastkey;
         }
       }
     }
-    s->M = M; s->nlegal = run_legal ? nlegal : 0; s->first_legal = first; s->result = result;
+    const bool capd = en_lane && lastkey >= 0;
+    const unsigned long long C = __ballot(capd), E = __ballot(en_lane);
+    const unsigned long long gmask = 0xFFFFull << (grp * 16);  // this lane's 16-lane group
+    int rank = 0;                                              // captured entries of my colour with a smaller key
+    for (int k = 0; k < 16; ++k) {
+      const int ok = __shfl(lastkey, (lane & 48) + k);
+      rank += (capd && ok >= 0 && ok < lastkey) ? 1 : 0;
+    }
+    const unsigned long long UC = E & ~C & gmask;
+    const int epos = capd ? __popcll(UC) + rank : __popcll(UC & lower);
+    // publish: scatter into the staging lists, then copy back
+    if (run_legal || phase1) {
+      if (own_lane) s->newlist[0][ownpos] = b->pl[turn][lane];
+      if (en_lane) s->newlist[grp][epos] = (uint8_t)esq;
+    }
+    __syncthreads();
+    if (run_legal || phase1) {
+      if (own_lane) b->pl[turn][lane] = s->newlist[0][lane];
+      if (en_lane) b->pl[ecol][e] = s->newlist[grp][e];
+    }
+    if (lane == 0) { s->M = M; s->nlegal = run_legal ? nlegal : 0; s->first_legal = first; s->result = result; }
   }
   __syncthreads();
 

@@ -61,7 +61,7 @@ struct fpc_engine {
   // asynchronous stage timing: events are only RECORDED on the stream during the search and read
   // back in fpc_search_results, so enabling it does not serialise the pipeline
   std::vector<hipEvent_t> evpool;
-  std::vector<int> evtag;          // 0 step start, 1 nn start, 2 expand start, 3 step end
+  std::vector<int> evtag;          // 0 step start, 1 tower start, 2 Linear start, 3 expand start, 4 step end
   size_t evused = 0;
 #ifndef FPC_EMUL
   fpc::NN nn;
@@ -187,7 +187,7 @@ void resolve_marks(fpc_engine *e) {
     if (b != a + 1) continue;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e->evpool[i], e->evpool[i + 1]) != hipSuccess) continue;
-    if (a == 0) e->stats.ms_select += ms; else if (a == 1) e->stats.ms_nn += ms; else e->stats.ms_expand += ms;
+    if (a == 0) e->stats.ms_select += ms; else if (a == 1) e->stats.ms_tower += ms; else if (a == 2) e->stats.ms_fc += ms; else e->stats.ms_expand += ms;
   }
   e->evused = 0;
 }
@@ -440,10 +440,10 @@ int fpc_search_select(fpc_engine *e, int *n_live, const float **enc_dev) {
 int fpc_search_expand(fpc_engine *e, const float *logits_dev, const float *value_dev) {
   if (!e || !e->searching) return fail(e, FPC_ESTATE, "fpc_search_begin has not been called");
   if (!logits_dev || !value_dev) return fail(e, FPC_EINVAL, "null logits/value");
-  mark(e, 2);
+  mark(e, 3);
   FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, logits_dev, value_dev);
   HIPCHK(e, hipGetLastError());
-  mark(e, 3);
+  mark(e, 4);
   e->stats.launches_expand++;
   return 0;
 }
@@ -461,11 +461,14 @@ int fpc_search_run(fpc_engine *e, int sims) {
                (const int *)e->t.leaf_slot, (const int *)e->t.leaf_turn, e->G, 1, (float *)nullptr, e->nn.input16(),
                e->nn.one16(), -1);
     mark(e, 1);
+    e->nn.mark_fn = [](void *ctx, int tag) { mark((fpc_engine *)ctx, tag); };
+    e->nn.mark_ctx = e;
     int r = e->nn.forward(e->G, &e->err);
+    e->nn.mark_fn = nullptr;
     if (r) return r;
-    mark(e, 2);
-    FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (const float *)e->nn.logits(), (const float *)e->nn.value());
     mark(e, 3);
+    FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (const float *)e->nn.logits(), (const float *)e->nn.value());
+    mark(e, 4);
     e->stats.launches_select++; e->stats.launches_nn++; e->stats.launches_expand++;
   }
   HIPCHK(e, hipGetLastError());

@@ -584,7 +584,8 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
     if (FPC_TOWER_VARIANT != 1 && FPC_TOWER_VARIANT != 2) { if (g_ + 1 < total) FPC_TSTORE(REGS_NEXT, (g_ + 1) % 3); } \
     if (tap_ == 8) {                                                                                 \
       __syncthreads();               /* every wave is done reading this layer's input image */       \
-      if (mode_ == 1) { FPC_VALUE_EPI(); }                                                           \
+      if (FPC_TOWER_VARIANT == 4) { asm volatile("" : "+v"(acc00), "+v"(acc01), "+v"(acc10), "+v"(acc11)); } \
+      else if (mode_ == 1) { FPC_VALUE_EPI(); }                                                      \
       else if (mode_ == 2) { FPC_TOWER_EPI(false, false); }   /* policy conv: ReLU rows in place */  \
       else if (l_ & 1) { FPC_TOWER_EPI(true, true); } else { FPC_TOWER_EPI(false, false); }          \
       FPC_ZERO_ACC();                                                                                \
@@ -856,6 +857,8 @@ struct NN {
   uint16_t *towerW = nullptr;    // [2*nblocks][9][128][128] contiguous copy for k_tower (F == 128)
   float *towerB = nullptr;
   bool use_tower = false;
+  void (*mark_fn)(void *, int) = nullptr;   // stage-timing hook of the engine (tag 2 = policy Linear starts)
+  void *mark_ctx = nullptr;
   float vb = 0.f;
   bool attr_set[2] = {false, false};
 
@@ -1038,6 +1041,7 @@ struct NN {
       if ((rc = conv(pconv, act[cur], F, nullptr, xfc, Kp, dc.A_ch, 1))) return rc;
       if ((rc = conv(vconv, act[cur], F, nullptr, yv, 32, 24, 0))) return rc;
     }
+    if (mark_fn) mark_fn(mark_ctx, 2);
     {
       FcArgs f{};
       f.X = xfc; f.Wf = fcw; f.part = fc_part; f.Kp = Kp; f.Np = Np; f.ksteps = Kp / 16; f.splitk = FC_SPLITK; f.Mtot = Gpad;

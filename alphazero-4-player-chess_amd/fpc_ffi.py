@@ -35,7 +35,7 @@ class Config(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("ms_select", C.c_double), ("ms_nn", C.c_double), ("ms_expand", C.c_double),
+    _fields_ = [("ms_select", C.c_double), ("ms_tower", C.c_double), ("ms_fc", C.c_double), ("ms_expand", C.c_double),
                 ("launches_select", C.c_uint64), ("launches_nn", C.c_uint64), ("launches_expand", C.c_uint64),
                 ("sims", C.c_uint64), ("nodes", C.c_uint64)]
 

@@ -184,13 +184,25 @@ def main():
             dist.destroy_process_group()
         return
 
-    fwd = int(st["launches_nn"])
-    flops_fwd = 2.0 * nn_macs(R, args.blocks, args.hidden) * G
-    nn_ms = st["ms_nn"] / max(fwd, 1)
-    achieved = flops_fwd / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else 0.0
-    tree_ms = (st["ms_select"] + st["ms_expand"]) / max(fwd, 1)
+    fwd = max(int(st["launches_nn"]), 1)
+    A_ch = 8 * R + 8
+    A = A_ch * R * R
+    F, Nb = args.hidden, args.blocks
+    flops_tower = 2.0 * 9 * R * R * (24 * F + 2 * Nb * F * F + F * A_ch + 24 * F) * G      # SURVEY 8(d), convs incl. both heads
+    flops_fc = 2.0 * (A * A + 24 * R * R) * G                                             # policy + value Linear
+    tower_ms, fc_ms = st["ms_tower"] / fwd, st["ms_fc"] / fwd
+    sel_ms, exp_ms = st["ms_select"] / fwd, st["ms_expand"] / fwd
+    peak = PEAK_TFLOPS[args.dtype]
+    ach_tower = flops_tower / (tower_ms * 1e-3) / 1e12 if tower_ms > 0 else 0.0
+    ach_fc = flops_fc / (fc_ms * 1e-3) / 1e12 if fc_ms > 0 else 0.0
+    pmc = {}
+    try:     # HBM bytes per launch measured with rocprofv3 --pmc (tools/pmc_nn.sh), committed under profiles/
+        pmc = json.load(open(os.path.join(HERE, "profiles", "pmc_summary.json")))
+    except Exception:
+        pass
+    tree_ms = sel_ms + exp_ms
     out = {
-        "metric": "MCTS simulations/sec (whole node), 256 games x 400 sims, 10-block ResNet",
+        "metric": baseline_metric(),
         "value": total / elapsed, "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -198,20 +210,35 @@ def main():
                    % (G, sims, args.blocks, args.hidden, R, R, "STANDARD" if R == 14 else "default"),
                    "games_per_gpu": G, "sims_per_move": sims, "board": R, "parallelism": "games sharded, %d/GPU" % G,
                    "tuple_allgather_bytes": gathered},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_TFLOPS[args.dtype], "traffic": None,
-                     "kernel": "k_gemm16 x%d launches per network forward (implicit-GEMM convs + policy Linear)" % (2 * args.blocks + 4),
-                     "flops_per_forward": flops_fwd, "ms_per_forward": nn_ms},
-        "stage_ms_per_sim_step": {"select+encode": st["ms_select"] / max(fwd, 1), "network": nn_ms,
-                                  "expand+backup": st["ms_expand"] / max(fwd, 1)},
-        "tree_hbm": {"algorithmic_bytes_per_sim": tree_bytes_per_sim(R), "achieved_GBps":
-                     tree_bytes_per_sim(R) * G / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0, "peak_GBps": PEAK_HBM_GBS},
+        # dominant kernel: k_tower = stem + 2*Nb residual convs + both head convs, one launch per network forward
+        "roofline": {"bound": "mfma", "achieved": ach_tower, "peak": peak, "unit": "TFLOP/s", "frac": ach_tower / peak,
+                     "traffic": pmc.get("k_tower", {}).get("hbm_bytes"),
+                     "kernel": "k_tower (residual tower megakernel, LDS-resident activations)",
+                     "flops_per_launch": flops_tower, "ms_per_launch": tower_ms},
+        "roofline_policy_linear": {"bound": "mfma", "achieved": ach_fc, "peak": peak, "unit": "TFLOP/s", "frac": ach_fc / peak,
+                                   "traffic": pmc.get("k_fc256", {}).get("hbm_bytes"),
+                                   "kernel": "k_fc256 + k_fc_reduce (weight-streaming Linear, 1.1 GB of bf16 weights per launch)",
+                                   "flops_per_launch": flops_fc, "ms_per_launch": fc_ms,
+                                   "weight_stream_GBps": (2.0 * ((A + 127) // 128 * 128) * ((A + 63) // 64 * 64)) / (fc_ms * 1e-3) / 1e9 if fc_ms > 0 else 0.0},
+        "stage_ms_per_sim_step": {"select+encode": sel_ms, "tower": tower_ms, "policy_linear": fc_ms, "expand+backup": exp_ms},
+        "tree_hbm": {"bound": "hbm", "algorithmic_bytes_per_sim": tree_bytes_per_sim(R),
+                     "achieved": tree_bytes_per_sim(R) * G / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0,
+                     "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": (tree_bytes_per_sim(R) * G / (tree_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if tree_ms > 0 else 0.0,
+                     "kernels": "k_select + k_encode + k_expand (latency-bound: one wavefront per game)"},
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(R, INV, model, args)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def baseline_metric():
+    try:
+        return json.load(open(os.path.join(HERE, "BASELINE.json")))["metric"]
+    except Exception:
+        return "MCTS simulations/sec (whole node), 256 games x 400 sims, 10-block ResNet"
 
 
 def host_cores():
@@ -235,7 +262,7 @@ def cpu_baseline(R, INV, model, args):
     cores = host_cores()
     torch.set_num_threads(cores)
     turn, entries = positions.start_entries(R)
-    Gc, sc = 4, 8
+    Gc, sc = 16, 100
     boards = [orc.board_from_dict(R, turn, [list(e) for e in entries]) for _ in range(Gc)]
 
     def ev(enc):

@@ -155,7 +155,10 @@ int fpc_nn_forward(fpc_engine *e, const float *enc_dev, int n, float *logits_dev
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------- */
 typedef struct fpc_stats {
-  double ms_select, ms_nn, ms_expand;   /* HIP-event time accumulated since fpc_stats_reset */
+  /* HIP-event time (events recorded on the engine's stream, resolved in fpc_search_results)
+   * accumulated since fpc_stats_reset: select+encode | residual tower incl. head convs |
+   * policy Linear (+ split-K reduce) | expand+backup */
+  double ms_select, ms_tower, ms_fc, ms_expand;
   uint64_t launches_select, launches_nn, launches_expand;
   uint64_t sims;                        /* leaf evaluations + terminal backups */
   uint64_t nodes;                       /* nodes allocated */

@@ -250,6 +250,59 @@ def main():
         searches.append(run_search([q5(), new_board()], "hash", 100))
     G["searches"] = searches
 
+    # ---- 5. full self-play traces: the reference's play() loop (alphazero.py:81-178) restated here
+    #         (alphazero.py itself cannot be imported) around the REAL MCTS.search /
+    #         TakeAction / GetGameResult / CalculateHeuristic, with the multinomial draw replaced by
+    #         the explicit inverse-CDF rule of alphazero-4-player-chess_amd/selfplay.py
+    sys.path.insert(0, os.path.join(REPO, "alphazero-4-player-chess_amd"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fpc_selfplay_rule", os.path.join(REPO, "alphazero-4-player-chess_amd", "selfplay.py"))
+    # only sample_action is needed; the module imports fpc_ffi (ctypes only), harmless here
+    rule = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rule)
+
+    def selfplay_trace(kind, n_games, sims, max_len, temperature, hw, seed):
+        margs = {"pool_size": 10, "C": 3.0, "num_searches": sims}
+        mcts = MCTS(FourPlayerChess, Eval(kind), margs)
+        rs = random.Random(seed)
+        uniforms = [[rs.random() for _ in range(n_games)] for _ in range(max_len)]
+        states = [new_board() for _ in range(n_games)]
+        ids = list(range(n_games))
+        games = {g: {"moves": [], "pi": [], "turns": [], "z": None, "result": 0} for g in ids}
+        for ply in range(max_len):
+            if not states:
+                break
+            roots = mcts.search(states)
+            for i in reversed(range(len(states))):
+                st = states[i]
+                g = ids[i]
+                ch = [[c.GetMoveMade().GetFlatIndex(), c.GetVisitCount()] for c in roots[i].GetChildren()]
+                games[g]["pi"].append(ch)
+                games[g]["turns"].append(int(st.GetTurn().GetColor()))
+                act = rule.sample_action([c[0] for c in ch], [c[1] for c in ch], temperature, uniforms[ply][g])
+                games[g]["moves"].append(act)
+                nxt = st.TakeAction(az.Move(act))
+                res = int(nxt.GetGameResult())
+                if res != 0:
+                    losing_team = int(st.GetTurn().GetTeam())
+                    games[g]["result"] = res
+                    games[g]["z"] = [1.0 if (t % 2) != losing_team else -1.0 for t in games[g]["turns"]]
+                    del states[i]
+                    del ids[i]
+                else:
+                    states[i] = nxt
+        for st, g in zip(states, ids):
+            curr_team = int(st.GetTurn().GetTeam())
+            h = st.CalculateHeuristic(st.GetTurn().GetTeam()) * hw
+            games[g]["z"] = [h if (t % 2) == curr_team else -h for t in games[g]["turns"]]
+            games[g]["final"] = snapshot(st)
+        return {"kind": kind, "n_games": n_games, "sims": sims, "max_len": max_len, "temperature": temperature,
+                "heuristic_weight": hw, "uniforms": uniforms, "games": [games[g] for g in range(n_games)]}
+
+    G["selfplay"] = [selfplay_trace("hash", 4, 24, 60 if R == 8 else 16, 1.1, 0.02, 99),
+                     selfplay_trace("zero", 3, 16, 40 if R == 8 else 10, 1.1, 0.02, 7)]
+    print("selfplay traces:", [(len(g["moves"]), g["result"]) for t in G["selfplay"] for g in t["games"]])
+
     path = os.path.join(args.out, "ref_r%d.json.gz" % R)
     os.makedirs(args.out, exist_ok=True)
     with gzip.open(path, "wt") as f:

@@ -191,3 +191,34 @@ def case_search_random_vs_oracle(backend, R, n_games, sims, seed, kind="hash"):
     _compare_search(res, oref, ("random", R, seed))
     eng.close()
     return "ok"
+
+
+def case_selfplay_trace(backend, R, max_traces=None):
+    """Whole self-play episodes (the play() loop of alphazero.py:81-178 around MCTS.search,
+    TakeAction, GetGameResult, CalculateHeuristic) against traces recorded from the real reference:
+    every move, every pi (child visit counts), results, z targets (quirk Q12) and final positions."""
+    import selfplay
+    g = gold(R)
+    INV = g["INV"]
+    st = g["start"]
+    n_checked = 0
+    for ti, tr in enumerate(g["selfplay"][:max_traces]):
+        ev = evaluators.make(tr["kind"], R)
+        n = tr["n_games"]
+        eng = make_engine(backend, R, INV, max_games=n, max_sims=tr["sims"])
+        start = [fpc_ffi.board_from_dict(R, st["turn"], [tuple(e) for e in st["dict"]], _lib=eng.L) for _ in range(n)]
+        args = {"temperature": tr["temperature"], "max_game_length": tr["max_len"], "heuristic_weight": tr["heuristic_weight"]}
+
+        def search_fn(pods):
+            return run_external_search(eng, backend, pods, tr["sims"], 3.0, ev)
+
+        eps = selfplay.play(search_fn, eng, start, args, tr["uniforms"])
+        for e, ref in zip(eps, tr["games"]):
+            assert e.moves == ref["moves"], (ti, e.gid)
+            assert e.result == ref["result"], (ti, e.gid)
+            assert [[[int(f), int(v)] for f, v in zip(fl, vi)] for _, fl, vi in e.entries] == ref["pi"], (ti, e.gid)
+            assert [b.turn for b, _, _ in e.entries] == ref["turns"]
+            assert [float(z) for z in e.z] == [float(z) for z in ref["z"]], (ti, e.gid, e.z[:4], ref["z"][:4])
+            n_checked += len(e.moves)
+        eng.close()
+    return n_checked

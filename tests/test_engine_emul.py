@@ -31,3 +31,7 @@ def test_search_golden_r14():
 
 def test_search_random_vs_oracle():
     ec.case_search_random_vs_oracle("emul", 8, n_games=5, sims=40, seed=11)
+
+
+def test_selfplay_trace_r8():
+    assert ec.case_selfplay_trace("emul", 8, max_traces=2) > 100

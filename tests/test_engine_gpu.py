@@ -34,3 +34,8 @@ def test_search_golden(R):
                                                     (14, 32, 100, 3, "ramp"), (8, 32, 120, 4, "hashinf")])
 def test_search_random_vs_oracle(R, games, sims, seed, kind):
     ec.case_search_random_vs_oracle("gpu", R, n_games=games, sims=sims, seed=seed, kind=kind)
+
+
+@pytest.mark.parametrize("R", [8, 14])
+def test_selfplay_trace(R):
+    assert ec.case_selfplay_trace("gpu", R) > 100

@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--board", type=int, default=14)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N>1 rehearsal on a single-GPU box: every rank uses device 0 (use with --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,9 +101,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
+    if args.rehearse_one_gpu:
+        local = 0
     if world > 1:
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     import fpc_ffi
     import net
     import positions

@@ -277,7 +277,7 @@ int fpc_board_heuristic(const fpc_board *b, int team) {   // engine/board.cpp:12
 int fpc_create(const fpc_config *cfg, fpc_engine **out) {
   if (!cfg || !out) return fail(nullptr, FPC_EINVAL, "null argument");
   const int R = cfg->board_size, INV = cfg->invalid_area;
-  if (R < 6 || R > 14 || (R & 1) || INV < 1 || 2 * INV >= R) return fail(nullptr, FPC_EINVAL, "unsupported board %dx%d/%d", R, R, INV);
+  if (R < 6 || R > 14 || INV < 1 || 2 * INV >= R) return fail(nullptr, FPC_EINVAL, "unsupported board %dx%d/%d", R, R, INV);
   if (cfg->max_games < 1 || cfg->max_sims < 1) return fail(nullptr, FPC_EINVAL, "max_games/max_sims must be positive");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device || cfg->device < 0)

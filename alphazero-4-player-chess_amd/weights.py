@@ -47,7 +47,7 @@ def export_weights(model, dtype=0):
     R = int(round(RR ** 0.5))
     assert R * R == RR and fc.weight.shape[1] == A
     Np = (A + 127) // 128 * 128
-    Kp = (A + 63) // 64 * 64
+    Kp = (A + 511) // 512 * 512      # k_fc256: K/16 k-steps, split-K 4, 2 per stage, 4 stages per unrolled iteration
     secs = []
     w, b = _fold(model.startBlock[0], model.startBlock[1])
     Fp = (F + 127) // 128 * 128

@@ -227,7 +227,7 @@ def main():
                                    "traffic": pmc.get("k_fc256", {}).get("hbm_bytes"),
                                    "kernel": "k_fc256 + k_fc_reduce (weight-streaming Linear, 1.1 GB of bf16 weights per launch)",
                                    "flops_per_launch": flops_fc, "ms_per_launch": fc_ms,
-                                   "weight_stream_GBps": (2.0 * ((A + 127) // 128 * 128) * ((A + 63) // 64 * 64)) / (fc_ms * 1e-3) / 1e9 if fc_ms > 0 else 0.0},
+                                   "weight_stream_GBps": (2.0 * ((A + 127) // 128 * 128) * ((A + 511) // 512 * 512)) / (fc_ms * 1e-3) / 1e9 if fc_ms > 0 else 0.0},
         "stage_ms_per_sim_step": {"select+encode": sel_ms, "tower": tower_ms, "policy_linear": fc_ms, "expand+backup": exp_ms},
         "tree_hbm": {"bound": "hbm", "algorithmic_bytes_per_sim": tree_bytes_per_sim(R),
                      "achieved": tree_bytes_per_sim(R) * G / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0,

@@ -222,3 +222,42 @@ def case_selfplay_trace(backend, R, max_traces=None):
             n_checked += len(e.moves)
         eng.close()
     return n_checked
+
+
+def case_other_sizes_vs_oracle(backend, R, INV, n_games=6, sims=40, seed=5):
+    """10x10/2 and 13x13/3 (the reference's other start layouts, start_fens.py:18-56): no compiled
+    reference exists for them, so the engine is compared with the oracle (pinned at 8 and 14)."""
+    import random
+    import positions
+    turn, entries = positions.start_entries(R)
+    rng = random.Random(seed)
+    eng = make_engine(backend, R, INV, max_games=n_games, max_sims=sims)
+    roots_o = []
+    for _ in range(n_games):
+        b = orc.board_from_dict(R, turn, [list(e) for e in entries])
+        fb = fpc_ffi.board_from_dict(R, turn, entries, _lib=eng.L)
+        assert fpc_ffi.lists_of(fb) == orc.lists_of(b)
+        for _ply in range(rng.randrange(0, 30)):
+            r_e, r_o = eng.game_result([fb])[0], orc.game_result(b, R, INV)
+            assert r_e == r_o
+            if r_o != 0:
+                break
+            lm_e = expand_promos(eng.legal_moves([fb])[0])
+            lm_o = orc.legal_moves(b, R, INV)
+            assert lm_e == lm_o and fpc_ffi.lists_of(fb) == orc.lists_of(b)
+            flats = sorted(set(x[2] for x in lm_o))
+            pick = flats[rng.randrange(len(flats))]
+            b, rc = orc.take_action(b, R, pick)
+            fb = eng.take_action([fb], [pick])[0]
+            assert rc == 0 and fpc_ffi.lists_of(fb) == orc.lists_of(b)
+        if orc.game_result(orc.clone(b), R, INV) != 0:
+            b = orc.board_from_dict(R, turn, [list(e) for e in entries])
+        roots_o.append(b)
+    ev = evaluators.make("hash", R)
+    rc, oref = orc.search([orc.clone(b) for b in roots_o], R, INV, sims, 3.0, ev)
+    assert rc == 0
+    roots = [fpc_ffi.board_from_lists(R, b.turn, orc.lists_of(b)) for b in roots_o]
+    res = run_external_search(eng, backend, roots, sims, 3.0, ev)
+    _compare_search(res, oref, ("size", R))
+    eng.close()
+    return True

@@ -35,3 +35,8 @@ def test_search_random_vs_oracle():
 
 def test_selfplay_trace_r8():
     assert ec.case_selfplay_trace("emul", 8, max_traces=2) > 100
+
+
+@pytest.mark.parametrize("R,INV", [(10, 2), (13, 3)])
+def test_other_board_sizes_vs_oracle(R, INV):
+    assert ec.case_other_sizes_vs_oracle("emul", R, INV, n_games=3, sims=20)

@@ -39,3 +39,8 @@ def test_search_random_vs_oracle(R, games, sims, seed, kind):
 @pytest.mark.parametrize("R", [8, 14])
 def test_selfplay_trace(R):
     assert ec.case_selfplay_trace("gpu", R) >= 94
+
+
+@pytest.mark.parametrize("R,INV", [(10, 2), (13, 3)])
+def test_other_board_sizes_vs_oracle(R, INV):
+    assert ec.case_other_sizes_vs_oracle("gpu", R, INV, n_games=24, sims=80)

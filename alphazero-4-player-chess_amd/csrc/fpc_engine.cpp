@@ -120,7 +120,7 @@ int ensure_board_scratch(fpc_engine *e, int n) {
 int check_boards(fpc_engine *e, const fpc_board *b, int n) {
   for (int i = 0; i < n; ++i) {
     for (int c = 0; c < 4; ++c) {
-      if (b[i].castle[c]) return fail(e, FPC_EUNSUPPORTED, "board %d: castling rights are set; the device path supports only the all-false rights the reference's FEN path produces (fen_parser.py:137-170)", i);
+      if (b[i].castle[c] > 3) return fail(e, FPC_EINVAL, "board %d: bad castling rights", i);
       if (b[i].plen[c] > FPC_MAX_PL) return fail(e, FPC_EINVAL, "board %d: piece list longer than %d", i, FPC_MAX_PL);
     }
     if (b[i].turn > 3) return fail(e, FPC_EINVAL, "board %d: bad turn", i);

@@ -58,6 +58,7 @@ struct __attribute__((aligned(16))) WaveLds {
   uint8_t mcap[FPC_MAX_MOVES];
   uint8_t mflag[FPC_MAX_MOVES];        // bit0 legal, bit1 promotion (reference emits 4 variants)
   uint8_t mpiece[FPC_MAX_MOVES];       // piece-list position of the mover (generation order key)
+  uint8_t mrook[FPC_MAX_MOVES];        // castling: the rook's square (it hops to from + (to-from)/2), else FPC_NO_SQ
   uint16_t lflat[FPC_MAX_MOVES];       // flat index of legal moves, reference order
   uint16_t lsorted[FPC_MAX_MOVES];     // ascending
   uint8_t lidx[FPC_MAX_MOVES];         // pseudo-move index of k-th legal move
@@ -202,12 +203,13 @@ __device__ __forceinline__ bool make_move_lane0(fpc_board *b, int from, int to) 
 }
 
 // IsAttackedByTeam(team, ksq) on the position obtained from `b` by moving the piece on `from` to
-// `to` (virtual make; from==to==FPC_NO_SQ -> the position itself).  engine/board.cpp:606-787.
+// `to` -- and, for castling, the rook on `from2` to `to2` -- (virtual make; FPC_NO_SQ squares -> the
+// position itself).  engine/board.cpp:606-787.
 __device__ inline bool attacked_virtual(const fpc_board *b, const DevCfg &c, int from, int to, uint8_t mover,
-                                        int ksq, int team) {
+                                        int from2, int to2, uint8_t mover2, int ksq, int team) {
   const int R = c.R;
   const int kr = ksq / R, kc = ksq % R;
-#define FPC_VSQ(q) ((q) == from ? (uint8_t)0 : ((q) == to ? mover : b->sq[(q)]))
+#define FPC_VSQ(q) (((q) == from || (q) == from2) ? (uint8_t)0 : ((q) == to ? mover : ((q) == to2 ? mover2 : b->sq[(q)])))
   // rooks & queens: rays end at the ARRAY edge, not at the cut corners (:632)
   for (int d = 0; d < 4; ++d) {
     const int ri = d == 0 ? -1 : d == 1 ? 1 : 0, ci = d == 2 ? -1 : d == 3 ? 1 : 0;
@@ -382,6 +384,42 @@ __device__ inline void walk_slot(const fpc_board *b, const DevCfg &c, int from, 
   }
 }
 
+// Castling (engine/board.cpp:343-465), generated after the king's eight steps, queenside first:
+// rights bit set, a same-team rook on the expected square, empty squares between, and neither the
+// king's square nor the first square it crosses attacked.  emit(to, rook_from).  The move travels as
+// a plain two-square king move through the tree (Move(flat) drops the rook hop); only
+// GetLegalMoves/GetGameResult execute the hop (virtually, for the legality test) and reorder lists.
+template <class F>
+__device__ inline void walk_castle(const fpc_board *b, const DevCfg &c, int from, F &&emit) {
+  const uint8_t king = b->sq[from];
+  const int colour = colour_of(king), team = team_of(king);
+  const uint8_t cur = b->castle[colour];
+  if (!(cur & 3)) return;
+  const int R = c.R, fr = from / R, fc = from % R;
+  for (int is_k = 0; is_k < 2; ++is_k) {
+    if (!(is_k ? (cur & 1) : (cur & 2))) continue;
+    int ur = 0, uc = 0;
+    switch (colour) {
+      case 0: uc = is_k ? 1 : -1; break;
+      case 1: ur = is_k ? 1 : -1; break;
+      case 2: uc = is_k ? -1 : 1; break;
+      default: ur = is_k ? -1 : 1; break;
+    }
+    const int nb = is_k ? 2 : 3;
+    const int rr = fr + ur * (nb + 1), rc = fc + uc * (nb + 1);
+    if (!in_array(c, rr, rc)) continue;                 // reference reads out of bounds here
+    const uint8_t rook = b->sq[rr * R + rc];
+    if (!present(rook) || type_of(rook) != ROOK || team_of(rook) != team) continue;
+    bool blocked = false;
+    for (int k = 1; k <= nb; ++k) blocked |= present(b->sq[(fr + ur * k) * R + fc + uc * k]);
+    if (blocked) continue;
+    const int b0 = (fr + ur) * R + fc + uc;
+    if (attacked_virtual(b, c, FPC_NO_SQ, FPC_NO_SQ, 0, FPC_NO_SQ, FPC_NO_SQ, 0, b0, team ^ 1)) continue;
+    if (attacked_virtual(b, c, FPC_NO_SQ, FPC_NO_SQ, 0, FPC_NO_SQ, FPC_NO_SQ, 0, from, team ^ 1)) continue;
+    emit((fr + 2 * ur) * R + fc + 2 * uc, rr * R + rc);
+  }
+}
+
 // Wave-cooperative movegen + legality + (optionally) GetGameResult / GetLegalMoves side effects.
 //   do_result: run Board::GetGameResult(player) (engine/board.cpp:891-939) -> s->result, and apply
 //              the piece-list reordering of its make/undo loop (stops at the first legal move).
@@ -406,6 +444,7 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
     from = b->pl[turn][p];
     walk_slot(b, c, from, d0, [&](int, uint8_t, bool) { ++cnt0; });
     walk_slot(b, c, from, d0 + 1, [&](int, uint8_t, bool) { ++cnt1; });
+    if (d0 == 6 && type_of(b->sq[from]) == KING) walk_castle(b, c, from, [&](int, int) { ++cnt1; });
   }
   // exclusive wave scan of (cnt0+cnt1) in lane order == reference generation order
   int incl = cnt0 + cnt1;
@@ -428,12 +467,17 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
     auto put = [&](int to, uint8_t cap, bool promo) {
       if (w < FPC_MAX_MOVES) {
         s->mfrom[w] = (uint8_t)from; s->mto[w] = (uint8_t)to; s->mcap[w] = cap; s->mflag[w] = promo ? 2 : 0;
-        s->mpiece[w] = (uint8_t)p;
+        s->mpiece[w] = (uint8_t)p; s->mrook[w] = FPC_NO_SQ;
       }
       ++w;
     };
     walk_slot(b, c, from, d0, put);
     walk_slot(b, c, from, d0 + 1, put);
+    if (d0 == 6 && type_of(b->sq[from]) == KING)
+      walk_castle(b, c, from, [&](int to, int rook_from) {
+        put(to, (uint8_t)0, false);
+        if (w - 1 < FPC_MAX_MOVES) s->mrook[w - 1] = (uint8_t)rook_from;
+      });
   }
   __syncthreads();
 
@@ -449,7 +493,9 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
       int ksq = b->king[player];
       if (type_of(mover) == KING && colour_of(mover) == player) ksq = t;
       else if (ksq == t) ksq = FPC_NO_SQ;               // the player's king itself was captured
-      legal = ksq == FPC_NO_SQ ? true : !attacked_virtual(b, c, f, t, mover, ksq, enemy);
+      const int rf = s->mrook[i];                       // castling: the rook hops next to the king
+      const int rt = rf == FPC_NO_SQ ? FPC_NO_SQ : f + (t - f) / 2;
+      legal = ksq == FPC_NO_SQ ? true : !attacked_virtual(b, c, f, t, mover, rf, rt, rf == FPC_NO_SQ ? (uint8_t)0 : b->sq[rf], ksq, enemy);
       if (legal) s->mflag[i] |= 1;
     }
     const unsigned long long bal = __ballot(legal);
@@ -472,82 +518,75 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
       const uint8_t cap = s->mcap[first];                // only the FIRST legal move is inspected (Q13)
       if (present(cap) && type_of(cap) == KING) result = team_of(cap) == 0 ? FPC_WIN_BG : FPC_WIN_RY;
     } else {
-      const bool chk = attacked_virtual(b, c, FPC_NO_SQ, FPC_NO_SQ, 0, b->king[player], enemy);
+      const bool chk = attacked_virtual(b, c, FPC_NO_SQ, FPC_NO_SQ, 0, FPC_NO_SQ, FPC_NO_SQ, 0, b->king[player], enemy);
       result = !chk ? FPC_STALEMATE : (team_of_colour(player) == 0 ? FPC_WIN_BG : FPC_WIN_RY);
     }
   }
   const bool run_legal = do_legal && result == FPC_IN_PROGRESS;
 
   // ---- piece-list reorderings caused by the reference's make/undo loops, in closed form.
-  // Every make/undo pair moves the mover's entry, then the captured piece's entry, to the END of
-  // their lists (engine/board.cpp:977-1014,1028-1160).  GetGameResult does that for moves 0..upto
-  // (it returns at the first legal move), GetLegalMoves afterwards for ALL pseudo-legal moves,
-  // regenerated in the then-current list order.  Net effect:
-  //   own list   : [pieces without moves] [movers GetGameResult did not reach] [movers it reached],
-  //                each group in its previous order;
-  //   enemy lists: never-captured entries keep their order in front, capturable entries follow,
-  //                ordered by the LAST move that captures them (in GetLegalMoves' generation order:
-  //                post-GetGameResult position of the mover, then its per-piece move index).
+  // Every make/undo pair moves the mover's entry -- then, for castling, the rook's entry -- and the
+  // captured piece's entry to the END of their lists (engine/board.cpp:977-1014,1028-1160).
+  // GetGameResult does that for moves 0..upto (it returns at the first legal move), GetLegalMoves
+  // afterwards for ALL pseudo-legal moves, regenerated in the then-current list order.  Net effect on
+  // every list: entries no move touches keep their order in front; touched entries follow, ordered by
+  // the LAST move that touches them (key = position of that move in the loop's generation order).
   // Lanes 0-15 own the side-to-move entries, lanes 16-31 / 32-47 the entries of the two enemy colours.
   {
     const bool phase1 = do_result && player_has_king;
     const int upto = nlegal > 0 ? first : M - 1;
-    const int pfirst = (phase1 && upto >= 0) ? (int)s->mpiece[upto] : -1;
-    const unsigned long long nmask = nown >= 64 ? ~0ull : ((1ull << nown) - 1ull);
     const unsigned long long lower = (1ull << lane) - 1ull;
-    const bool own_lane = lane < nown && lane < FPC_MAX_PL;
-    const bool hasmv = own_lane && s->poff[lane + 1] > s->poff[lane];
-    const bool touched1 = hasmv && lane <= pfirst;
-    const unsigned long long T1 = __ballot(touched1), H = __ballot(hasmv);
-    const unsigned long long U1 = nmask & ~T1;
-    // position after GetGameResult's loop (identity when it did not run)
-    const int pos1 = touched1 ? __popcll(U1) + __popcll(T1 & lower) : __popcll(U1 & lower);
-    if (own_lane) s->l1pos[lane] = (uint8_t)(phase1 ? pos1 : lane);
-    int ownpos = lane;
-    if (run_legal) {
-      const unsigned long long G0 = nmask & ~H, G1 = H & ~T1, G2 = T1;
-      ownpos = !hasmv ? __popcll(G0 & lower)
-                      : (!touched1 ? __popcll(G0) + __popcll(G1 & lower) : __popcll(G0) + __popcll(G1) + __popcll(G2 & lower));
-    } else if (phase1) {
-      ownpos = pos1;
+    const int grp = lane >> 4, e = lane & 15;                  // grp 0: own list; 1, 2: enemy colours turn+1, turn+3
+    const int lcol = grp == 0 ? turn : (grp == 1 ? ((turn + 1) & 3) : ((turn + 3) & 3));
+    const bool my_lane = grp <= 2 && e < b->plen[lcol] && e < FPC_MAX_PL;
+    const int mysq = my_lane ? b->pl[lcol][e] : -1;
+    const unsigned long long gmask = 0xFFFFull << (grp * 16);
+    auto rank_in_group = [&](int key, bool touched) {          // touched entries of my list with a smaller key
+      int rank = 0;
+      for (int k = 0; k < 16; ++k) {
+        const int ok = __shfl(key, (lane & 48) + k);
+        rank += (touched && ok >= 0 && ok < key) ? 1 : 0;
+      }
+      return rank;
+    };
+    // GetGameResult's loop: key = move index
+    int lk1 = -1;
+    if (phase1 && my_lane) {
+      for (int i = 0; i <= upto; ++i) {
+        const bool rook_hit = grp == 0 && s->mrook[i] == mysq;   // the rook is re-appended AFTER the king
+        const bool hit = grp == 0 ? (s->mpiece[i] == e || rook_hit) : (present(s->mcap[i]) && s->mto[i] == mysq);
+        if (hit) lk1 = 2 * i + (rook_hit ? 1 : 0);
+      }
     }
-    __syncthreads();                          // l1pos visible
-    // enemy entries
-    const int grp = lane >> 4, e = lane & 15;                  // grp 1, 2: enemy colours turn+1, turn+3
-    const int ecol = grp == 1 ? ((turn + 1) & 3) : ((turn + 3) & 3);
-    const bool en_lane = (grp == 1 || grp == 2) && e < b->plen[ecol];
-    const int esq = en_lane ? b->pl[ecol][e] : -1;
-    int lastkey = -1;                                          // -1: not captured by the relevant loop
-    if (run_legal || phase1) {
-      const int lim = run_legal ? M : upto + 1;
-      for (int i = 0; i < lim; ++i) {
-        if (present(s->mcap[i]) && s->mto[i] == esq) {
+    const bool t1 = my_lane && lk1 >= 0;
+    const unsigned long long T1 = __ballot(t1), L = __ballot(my_lane);
+    const int r1 = rank_in_group(lk1, t1);
+    const unsigned long long U1 = L & ~T1 & gmask;
+    const int pos1 = t1 ? __popcll(U1) + r1 : __popcll(U1 & lower);
+    if (grp == 0 && my_lane) s->l1pos[e] = (uint8_t)(phase1 ? pos1 : e);
+    __syncthreads();
+    // GetLegalMoves' loop: key = (post-GetGameResult position of the mover, its per-piece move index)
+    int lk2 = -1;
+    if (run_legal && my_lane) {
+      for (int i = 0; i < M; ++i) {
+        const bool rook_hit = grp == 0 && s->mrook[i] == mysq;
+        const bool hit = grp == 0 ? (s->mpiece[i] == e || rook_hit) : (present(s->mcap[i]) && s->mto[i] == mysq);
+        if (hit) {
           const int pc = s->mpiece[i];
-          const int key = run_legal ? (int)s->l1pos[pc] * 256 + (i - (int)s->poff[pc]) : i;
-          lastkey = key > lastkey ? key : lastkey;
+          const int key = 2 * ((int)s->l1pos[pc] * 256 + (i - (int)s->poff[pc])) + (rook_hit ? 1 : 0);
+          lk2 = key > lk2 ? key : lk2;
         }
       }
     }
-    const bool capd = en_lane && lastkey >= 0;
-    const unsigned long long C = __ballot(capd), E = __ballot(en_lane);
-    const unsigned long long gmask = 0xFFFFull << (grp * 16);  // this lane's 16-lane group
-    int rank = 0;                                              // captured entries of my colour with a smaller key
-    for (int k = 0; k < 16; ++k) {
-      const int ok = __shfl(lastkey, (lane & 48) + k);
-      rank += (capd && ok >= 0 && ok < lastkey) ? 1 : 0;
-    }
-    const unsigned long long UC = E & ~C & gmask;
-    const int epos = capd ? __popcll(UC) + rank : __popcll(UC & lower);
-    // publish: scatter into the staging lists, then copy back
-    if (run_legal || phase1) {
-      if (own_lane) s->newlist[0][ownpos] = b->pl[turn][lane];
-      if (en_lane) s->newlist[grp][epos] = (uint8_t)esq;
-    }
+    const bool t2 = my_lane && lk2 >= 0;
+    const unsigned long long T2 = __ballot(t2);
+    const int r2 = rank_in_group(lk2, t2);
+    const unsigned long long U2 = L & ~T2 & gmask;
+    const int pos2 = t2 ? __popcll(U2) + r2 : __popcll(U2 & lower);
+    const int newpos = run_legal ? pos2 : pos1;
+    if ((run_legal || phase1) && my_lane) s->newlist[grp][newpos] = (uint8_t)mysq;
     __syncthreads();
-    if (run_legal || phase1) {
-      if (own_lane) b->pl[turn][lane] = s->newlist[0][lane];
-      if (en_lane) b->pl[ecol][e] = s->newlist[grp][e];
-    }
+    if ((run_legal || phase1) && my_lane) b->pl[lcol][e] = s->newlist[grp][e];
     if (lane == 0) { s->M = M; s->nlegal = run_legal ? nlegal : 0; s->first_legal = first; s->result = result; }
   }
   __syncthreads();

@@ -261,3 +261,56 @@ def case_other_sizes_vs_oracle(backend, R, INV, n_games=6, sims=40, seed=5):
     _compare_search(res, oref, ("size", R))
     eng.close()
     return True
+
+
+def case_castling_vs_oracle(backend, n_games=4, plies=40, sims=30, seed=21):
+    """Castling (engine/board.cpp:343-465).  NOT reachable through the reference's Python boundary:
+    `Board(turn, l2p, castling_rights)` needs a dict keyed by Player, and the bound Player type is
+    unhashable (wrapper.cpp:81-87 defines == without __hash__), while fen_parser drops the rights
+    (Q10) -- so no golden vector can exist.  The C-ABI accepts rights; the device implementation is
+    held against the oracle's restatement: 14x14 start without knights/bishops/queens, all rights set."""
+    import random
+    import positions
+    R, INV = 14, 3
+    turn, entries = positions.start_entries(R)
+    entries = [e for e in entries if e[2] in (positions.PAWN, positions.ROOK, positions.KING)]
+    rng = random.Random(seed)
+    eng = make_engine(backend, R, INV, max_games=n_games, max_sims=sims)
+    n_castle = 0
+    roots_o = []
+    for _ in range(n_games):
+        b = orc.board_from_dict(R, turn, [list(e) for e in entries], castle=[3, 3, 3, 3])
+        fb = fpc_ffi.board_from_dict(R, turn, entries, castle=[3, 3, 3, 3], _lib=eng.L)
+        assert fpc_ffi.lists_of(fb) == orc.lists_of(b)
+        for _ply in range(plies):
+            r_e, r_o = eng.game_result([fb])[0], orc.game_result(b, R, INV)
+            assert r_e == r_o and fpc_ffi.lists_of(fb) == orc.lists_of(b)
+            if r_o != 0:
+                break
+            lm_e = expand_promos(eng.legal_moves([fb])[0])
+            lm_o = orc.legal_moves(b, R, INV)
+            assert lm_e == lm_o, (_ply, lm_e, lm_o)
+            assert fpc_ffi.lists_of(fb) == orc.lists_of(b)
+            kings = [b.king[c] for c in range(4)]
+            castles = [m for m in lm_o if m[0] in kings and max(abs(m[0] // R - m[1] // R), abs(m[0] % R - m[1] % R)) == 2]
+            n_castle += len(castles)
+            flats = sorted(set(x[2] for x in lm_o))
+            pick = castles[0][2] if castles and rng.random() < 0.5 else flats[rng.randrange(len(flats))]
+            b, rc = orc.take_action(b, R, pick)
+            fb = eng.take_action([fb], [pick])[0]
+            assert rc == 0 and fpc_ffi.lists_of(fb) == orc.lists_of(b)
+        roots_o.append(orc.board_from_dict(R, turn, [list(e) for e in entries], castle=[3, 3, 3, 3]) if orc.game_result(orc.clone(b), R, INV) != 0 else b)
+    assert n_castle > 0
+    ev = evaluators.make("hash", R)
+    rc, oref = orc.search([orc.clone(b) for b in roots_o], R, INV, sims, 3.0, ev)
+    assert rc == 0
+    roots = []
+    for b in roots_o:
+        fb = fpc_ffi.board_from_lists(R, b.turn, orc.lists_of(b))
+        for c in range(4):
+            fb.castle[c] = b.castle[c]
+        roots.append(fb)
+    res = run_external_search(eng, backend, roots, sims, 3.0, ev)
+    _compare_search(res, oref, ("castling",))
+    eng.close()
+    return n_castle

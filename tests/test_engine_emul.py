@@ -40,3 +40,7 @@ def test_selfplay_trace_r8():
 @pytest.mark.parametrize("R,INV", [(10, 2), (13, 3)])
 def test_other_board_sizes_vs_oracle(R, INV):
     assert ec.case_other_sizes_vs_oracle("emul", R, INV, n_games=3, sims=20)
+
+
+def test_castling_vs_oracle():
+    assert ec.case_castling_vs_oracle("emul", n_games=2, plies=30, sims=16) > 0

@@ -44,3 +44,7 @@ def test_selfplay_trace(R):
 @pytest.mark.parametrize("R,INV", [(10, 2), (13, 3)])
 def test_other_board_sizes_vs_oracle(R, INV):
     assert ec.case_other_sizes_vs_oracle("gpu", R, INV, n_games=24, sims=80)
+
+
+def test_castling_vs_oracle():
+    assert ec.case_castling_vs_oracle("gpu", n_games=16, plies=80, sims=60) > 0

@@ -38,7 +38,7 @@ typedef enum fpc_status {
   FPC_EPOLICY = -5,     /* legal policy mass is 0/NaN: the reference expands every index and throws (mcts.py:76,84) */
   FPC_ECAPACITY = -6,   /* node/board pool or move buffer overflow (reference: abort(), engine/board.h:482-486) */
   FPC_EMOVE = -7,       /* engine/board.cpp:1046-1054 "piece missing for move" */
-  FPC_EUNSUPPORTED = -8,/* castling rights set (the reference's own FEN path never sets them) */
+  FPC_EUNSUPPORTED = -8,/* reserved */
   FPC_ESTATE = -9,      /* call sequence error */
   FPC_EWEIGHTS = -10    /* weight blob malformed / not loaded */
 } fpc_status;
@@ -59,7 +59,7 @@ typedef struct fpc_board {
   uint8_t pl[4][FPC_MAX_PL];
   uint8_t plen[4];
   uint8_t king[4];         /* king_locations_ (FPC_NO_SQ if captured) */
-  uint8_t castle[4];       /* bit0 kingside, bit1 queenside; must be 0 for device ops */
+  uint8_t castle[4];       /* bit0 kingside, bit1 queenside (constant through tree/self-play moves) */
   uint8_t turn;
   uint8_t pad[15];
 } fpc_board;               /* sizeof == 288 */

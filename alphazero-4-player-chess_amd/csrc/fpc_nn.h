@@ -10,9 +10,10 @@
 // (16x16 = 256 rows per game at 14x14), so a 3x3 convolution is an implicit GEMM whose nine taps
 // are nine row-shifted views of ONE matrix:  Y[m, co] = sum_t sum_ci X[m + off_t, ci] * W[t, co, ci]
 // -- no im2col, no bounds checks in the inner loop.  M = games*256 rows, N = Cout, K = 9*Cin.
-// One kernel template (k_gemm16) serves all convs and the policy Linear (ntaps = 1); tiles are
-// 128x128xBK, 4 waves (2x2) of 64x64, v_mfma_f32_32x32x16_{bf16,f16}, LDS double-buffered with a
-// 16-byte-chunk XOR swizzle that makes every ds_read_b128 fragment read conflict-free.
+// Kernels: k_tower (whole residual tower + head convs, activations LDS-resident, hidden = 128),
+// k_conv3x3 (one conv per launch, any hidden width), k_fc256 (weight-streaming policy Linear).
+// All use v_mfma_f32_32x32x16_{bf16,f16} and a 16-byte-chunk XOR swizzle in LDS that makes every
+// ds_read_b128 fragment read conflict-free.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -49,19 +50,6 @@ struct E16<1> {  // fp16
   }
 };
 
-struct GemmArgs {
-  const uint16_t *A;     // [rows][lda] 16-bit; conv: base already advanced past the guard rows
-  const uint16_t *B;     // [ntaps][N_pad][K_tap] 16-bit, K contiguous
-  const float *bias;     // [N_pad]
-  const uint16_t *Res;   // residual in the output's layout, or null
-  void *out;
-  int M, N_pad, K_tap, ntaps, lda, ldo;
-  int P, R, PP;          // padded grid edge, board edge, rows per game
-  int n_valid, m_valid;
-  int mode;              // 0: conv -> padded grid, ReLU (+Res)   1: policy conv -> compact FC input
-                         // 2: Linear -> f32 logits (+bias)
-};
-
 constexpr int GEMM_BM = 128, GEMM_BN = 128;
 constexpr int FC_SPLITK = 4;   // 736 blocks at 14x14: fine-grained enough for the dispatcher to balance 256 CUs
 
@@ -72,101 +60,6 @@ __device__ __forceinline__ int lds_off(int row, int j) {
   constexpr int CH = BK / 8;            // chunks per row
   constexpr int RPB = 256 / (BK * 2);   // tile rows per 256-B bank row
   return row * (BK * 2) + ((j ^ ((row / RPB) % CH)) << 4);
-}
-
-template <int DT, int BK>
-__global__ void __launch_bounds__(256) k_gemm16(GemmArgs g) {
-  constexpr int CH = BK / 8;
-  constexpr int NLD = (GEMM_BM * CH) / 256;   // 16-B chunks per thread per operand per stage
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char *As = smem;                                  // [2][128*BK*2]
-  unsigned char *Bs = smem + 2 * GEMM_BM * BK * 2;           // [2][128*BK*2]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * GEMM_BM, n0 = blockIdx.y * GEMM_BN;
-  const int ksteps = g.K_tap / BK, S = g.ntaps * ksteps;
-
-  u32x4_t ra[NLD], rb[NLD];
-#define FPC_GLOAD(S_)                                                                                   \
-  {                                                                                                     \
-    const int tap_ = (S_) / ksteps, k0_ = ((S_) % ksteps) * BK;                                         \
-    const int off_ = g.ntaps == 9 ? (tap_ / 3 - 1) * g.P + (tap_ % 3 - 1) : 0;                          \
-    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                   \
-      const int c_ = tid + 256 * i, row_ = c_ / CH, j_ = c_ % CH;                                       \
-      ra[i] = *reinterpret_cast<const u32x4_t *>(g.A + (long)(m0 + row_ + off_) * g.lda + k0_ + j_ * 8);  \
-      rb[i] = *reinterpret_cast<const u32x4_t *>(g.B + ((long)tap_ * g.N_pad + n0 + row_) * g.K_tap + k0_ + j_ * 8); \
-    }                                                                                                   \
-  }
-#define FPC_SSTORE(BUF_)                                                                                \
-  {                                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                   \
-      const int c_ = tid + 256 * i, row_ = c_ / CH, j_ = c_ % CH;                                       \
-      *reinterpret_cast<u32x4_t *>(As + (BUF_) * (GEMM_BM * BK * 2) + lds_off<BK>(row_, j_)) = ra[i];     \
-      *reinterpret_cast<u32x4_t *>(Bs + (BUF_) * (GEMM_BN * BK * 2) + lds_off<BK>(row_, j_)) = rb[i];     \
-    }                                                                                                   \
-  }
-
-  f32x16_t acc00, acc01, acc10, acc11;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
-
-  FPC_GLOAD(0);
-  FPC_SSTORE(0);
-  __syncthreads();
-  for (int s = 0; s < S; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < S) FPC_GLOAD(s + 1);
-    const unsigned char *Ab = As + buf * (GEMM_BM * BK * 2), *Bb = Bs + buf * (GEMM_BN * BK * 2);
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int j = ks * 2 + (lane >> 5);
-      const u32x4_t fa0 = *reinterpret_cast<const u32x4_t *>(Ab + lds_off<BK>(wm * 64 + (lane & 31), j));
-      const u32x4_t fa1 = *reinterpret_cast<const u32x4_t *>(Ab + lds_off<BK>(wm * 64 + 32 + (lane & 31), j));
-      const u32x4_t fb0 = *reinterpret_cast<const u32x4_t *>(Bb + lds_off<BK>(wn * 64 + (lane & 31), j));
-      const u32x4_t fb1 = *reinterpret_cast<const u32x4_t *>(Bb + lds_off<BK>(wn * 64 + 32 + (lane & 31), j));
-      acc00 = E16<DT>::mfma(fa0, fb0, acc00);
-      acc01 = E16<DT>::mfma(fa0, fb1, acc01);
-      acc10 = E16<DT>::mfma(fa1, fb0, acc10);
-      acc11 = E16<DT>::mfma(fa1, fb1, acc11);
-    }
-    if (s + 1 < S) FPC_SSTORE(buf ^ 1);
-    __syncthreads();
-  }
-#undef FPC_GLOAD
-#undef FPC_SSTORE
-
-  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int n = n0 + wn * 64 + b * 32 + (lane & 31);
-      const float bias = g.bias[n];
-      const f32x16_t accv = a == 0 ? (b == 0 ? acc00 : acc01) : (b == 0 ? acc10 : acc11);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float v = accv[r] + bias;
-        if (g.mode == 2) {
-          if (m < g.m_valid && n < g.n_valid) reinterpret_cast<float *>(g.out)[(long)m * g.ldo + n] = v;
-        } else {
-          const int game = m / g.PP, pos = m % g.PP, pi = pos / g.P, pj = pos % g.P;
-          const bool interior = pi >= 1 && pi <= g.R && pj >= 1 && pj <= g.R && game < g.m_valid;
-          if (interior && n < g.n_valid) {
-            if (g.mode == 0) {
-              if (g.Res) v += E16<DT>::to_f32(g.Res[(long)m * g.ldo + n]);
-              v = v > 0.f ? v : 0.f;
-              reinterpret_cast<uint16_t *>(g.out)[(long)m * g.ldo + n] = E16<DT>::from_f32(v);
-            } else {
-              v = v > 0.f ? v : 0.f;
-              const int q = (pi - 1) * g.R + (pj - 1);
-              reinterpret_cast<uint16_t *>(g.out)[(long)game * g.ldo + (long)q * g.n_valid + n] = E16<DT>::from_f32(v);
-            }
-          }
-        }
-      }
-    }
-  }
 }
 
 // ================================================================================================
@@ -379,12 +272,6 @@ struct TowerArgs {
   int L, P, R, PP, gpb, n_games, heads, Kp, A_ch;
 };
 
-#ifndef FPC_FC_VARIANT
-#define FPC_FC_VARIANT 0      // 1/2: timing experiments (no weight stream / no activation stream); results wrong
-#endif
-#ifndef FPC_TOWER_VARIANT
-#define FPC_TOWER_VARIANT 0   // 1/2: timing experiments (no weight reload / + no stage barrier); results wrong
-#endif
 constexpr int TOWER_F = 128, TOWER_THREADS = 512;
 constexpr int TOWER_IMG = 256 * TOWER_F * 2;            // 65536
 constexpr int TOWER_STAGE = 128 * 128 * 2;              // 32768: one tap
@@ -553,16 +440,11 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
   } else if (wn == 0) {   /* value conv: only the 32 live output columns */                          \
     acc00 = E16<DT>::mfma(A0, B0, acc00); acc10 = E16<DT>::mfma(A1, B0, acc10);                      \
   }
-#if FPC_TOWER_VARIANT == 3
-#define FPC_FRAGV(KS_, A0, A1, B0, B1) asm volatile("" : "+v"(A0), "+v"(A1), "+v"(B0), "+v"(B1));
-#else
-#define FPC_FRAGV(KS_, A0, A1, B0, B1) FPC_FRAG(KS_, A0, A1, B0, B1)
-#endif
 #define FPC_TSTEP(G_, REGS_NEXT, REGS_FREE, MODE_)   /* MODE_ literal: 0 tower layer, 1 value conv, 2 policy conv */ \
   {                                                                                                  \
     const int g_ = (G_), l_ = g_ / 9, tap_ = g_ % 9;                                                 \
     constexpr int mode_ = (MODE_);                                                                   \
-    if (FPC_TOWER_VARIANT != 1 && FPC_TOWER_VARIANT != 2) { if (g_ + 2 < total) FPC_TLOAD(REGS_FREE, g_ + 2); } \
+    if (g_ + 2 < total) FPC_TLOAD(REGS_FREE, g_ + 2);                                                \
     if (tap_ == 0) { bias0 = g.bt[l_ * 128 + wn * 64 + (lane & 31)]; bias1 = g.bt[l_ * 128 + wn * 64 + 32 + (lane & 31)]; } \
     const int arow_ = (tap_ / 3 - 1) * g.P + (tap_ % 3 - 1) + wm * 64 + (lane & 31);                 \
     const unsigned char *wb_ = ring + (g_ % 3) * TOWER_STAGE;                                        \
@@ -573,24 +455,23 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
     FPC_FRAG(0, pa0, pa1, pb0, pb1);                                                                 \
     FPC_FRAG(1, qa0, qa1, qb0, qb1);                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                               \
-    FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAGV(2, pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); \
-    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAGV(3, qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); \
-    FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAGV(4, pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); \
-    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAGV(5, qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); \
-    FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAGV(6, pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); \
-    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAGV(7, qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); \
+    FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(2, pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); \
+    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(3, qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); \
+    FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(4, pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); \
+    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(5, qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); \
+    FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(6, pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); \
+    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(7, qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); \
     FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0);                                  \
     FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0);                                  \
-    if (FPC_TOWER_VARIANT != 1 && FPC_TOWER_VARIANT != 2) { if (g_ + 1 < total) FPC_TSTORE(REGS_NEXT, (g_ + 1) % 3); } \
+    if (g_ + 1 < total) FPC_TSTORE(REGS_NEXT, (g_ + 1) % 3);                                         \
     if (tap_ == 8) {                                                                                 \
       __syncthreads();               /* every wave is done reading this layer's input image */       \
-      if (FPC_TOWER_VARIANT == 4) { asm volatile("" : "+v"(acc00), "+v"(acc01), "+v"(acc10), "+v"(acc11)); } \
-      else if (mode_ == 1) { FPC_VALUE_EPI(); }                                                      \
+      if (mode_ == 1) { FPC_VALUE_EPI(); }                                                           \
       else if (mode_ == 2) { FPC_TOWER_EPI(false, false); }   /* policy conv: ReLU rows in place */  \
       else if (l_ & 1) { FPC_TOWER_EPI(true, true); } else { FPC_TOWER_EPI(false, false); }          \
       FPC_ZERO_ACC();                                                                                \
     }                                                                                                \
-    if (FPC_TOWER_VARIANT != 2) __syncthreads();                                                     \
+    __syncthreads();                                                                                 \
   }
   const int tower_stages = g.L * 9;            // even
   for (int gs = 0; gs < tower_stages; gs += 2) {
@@ -608,7 +489,6 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
   }
 #undef FPC_TSTEP
 #undef FPC_FRAG
-#undef FPC_FRAGV
 #undef FPC_MMA
 #undef FPC_TLOAD
 #undef FPC_TSTORE
@@ -738,9 +618,9 @@ __global__ void __launch_bounds__(256, 2) k_fc256(FcArgs g) {
 #define FPC_FCSTEP(S_, WSLOT_, ANEXT_)                                                               \
   {                                                                                                  \
     FPC_FCMMA(S_, WSLOT_);                                                                           \
-    if (FPC_FC_VARIANT != 1) FPC_WLOADQ(WSLOT_, (S_) + 4);                                           \
-    if (FPC_FC_VARIANT != 2) { FPC_ASTORE(ANEXT_, ((S_) + 1) & 1);                                   \
-    FPC_ALOAD(ANEXT_, (S_) + 3); }                                                                   \
+    FPC_WLOADQ(WSLOT_, (S_) + 4);                                                                    \
+    FPC_ASTORE(ANEXT_, ((S_) + 1) & 1);                                                              \
+    FPC_ALOAD(ANEXT_, (S_) + 3);                                                                     \
     __syncthreads();                                                                                 \
   }
   int s = 0;
@@ -860,7 +740,6 @@ struct NN {
   void (*mark_fn)(void *, int) = nullptr;   // stage-timing hook of the engine (tag 2 = policy Linear starts)
   void *mark_ctx = nullptr;
   float vb = 0.f;
-  bool attr_set[2] = {false, false};
 
   template <class T>
   int dmalloc(T **p, size_t count, std::string *err) {
@@ -958,25 +837,6 @@ struct NN {
       use_tower = true;
     }
     loaded = true;
-    return 0;
-  }
-
-  template <int DT>
-  int launch_gemm(const GemmArgs &g, int bk, std::string *err) {
-    dim3 grid(g.M / GEMM_BM, g.N_pad / GEMM_BN), block(256);
-    const size_t lds = (size_t)2 * (GEMM_BM + GEMM_BN) * bk * 2;
-    if (!attr_set[DT]) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm16<DT, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (GEMM_BM + GEMM_BN) * 64 * 2);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm16<DT, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (GEMM_BM + GEMM_BN) * 32 * 2);
-      attr_set[DT] = true;
-    }
-    if (bk == 64) hipLaunchKernelGGL((k_gemm16<DT, 64>), grid, block, lds, stream, g);
-    else hipLaunchKernelGGL((k_gemm16<DT, 32>), grid, block, lds, stream, g);
-    const hipError_t le = hipGetLastError();
-    if (le != hipSuccess) {
-      *err = std::string("k_gemm16 launch failed: ") + hipGetErrorString(le) + " (grid " + std::to_string(grid.x) + "x" + std::to_string(grid.y) + ", lds " + std::to_string(lds) + ")";
-      return FPC_ENODEVICE;
-    }
     return 0;
   }
 

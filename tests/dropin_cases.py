@@ -94,3 +94,36 @@ def case_reference_style_usage(backend, R):
         game.AppendToMemory(az.MemoryEntry(game, action_probs / action_probs.sum()))
         assert len(game.GetMemory()) == 1
     return True
+
+
+def case_training_loop(backend, R=8):
+    """AlphaZero.learn(): self-play on the engine -> replay buffer -> PyTorch optimiser step ->
+    weights pushed back into the engine for the next search (N2/N3 of SURVEY 8f)."""
+    az = setup(backend, R)
+    from alphazero import AlphaZero
+    from fen_parser import parse_board_args_from_fen
+    from four_player_chess_board import FourPlayerChess
+    import net
+    torch.manual_seed(0)
+    model = net.ResNet(FourPlayerChess, 1, 64, "cpu")
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    args = {"C": 3, "num_searches": 8, "num_iterations": 1, "num_games": 4, "num_parallel_games": 4, "batch_size": 8,
+            "temperature": 1.1, "heuristic_weight": 0.02, "max_game_length": 6, "replay_buffer_capacity": 150,
+            "validation_buffer_capacity": 30, "pool_size": 10, "nn_dtype": 1}
+    evaluator = None
+    if backend == "emul":      # the emulator build has no MFMA network: plug the model in through the evaluator seam
+        class Wrap:
+            device = "cpu"
+
+            def __call__(self, x):
+                with torch.no_grad():
+                    return model(x)
+        evaluator = Wrap()
+    init = parse_board_args_from_fen(FourPlayerChess.start_fen, R)
+    a = AlphaZero(model, optimizer, FourPlayerChess, args, init, evaluator=evaluator, seed=3)
+    before = [p.detach().clone() for p in model.parameters()]
+    a.learn()
+    assert len(a.experience_buffer) + len(a.validation_buffer) == 2 * 4 * 6
+    assert a.history and all(np.isfinite(h["loss"]) for h in a.history)
+    assert any(not torch.equal(b, p.detach()) for b, p in zip(before, model.parameters()))
+    return len(a.history)

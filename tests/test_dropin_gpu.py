@@ -28,3 +28,7 @@ def test_native_resnet_search_through_mcts():
         assert sum(c.GetVisitCount() for c in r.GetChildren()) == len(r.GetChildren()) + 50 - 1    # quirk Q1
     first = [[c.GetMoveMade().GetFlatIndex(), c.GetVisitCount()] for c in roots[0].GetChildren()]
     assert all([[c.GetMoveMade().GetFlatIndex(), c.GetVisitCount()] for c in r.GetChildren()] == first for r in roots)
+
+
+def test_training_loop_native_network():
+    assert dc.case_training_loop("gpu") >= 1

@@ -196,7 +196,7 @@ void resolve_marks(fpc_engine *e) {
 
 extern "C" {
 
-int fpc_abi_version(void) { return 1; }
+int fpc_abi_version(void) { return 2; }
 
 const char *fpc_last_error(const fpc_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 

@@ -11,3 +11,13 @@ for p in (REPO, os.path.join(REPO, "tests"), os.path.join(REPO, "alphazero-4-pla
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    """Make sure the native pieces exist (fresh checkout: *.so are git-ignored).  Builds with hipcc /
+    g++ exactly like `python __graft_entry__.py`; a no-op when everything is up to date."""
+    import __graft_entry__
+    try:
+        __graft_entry__.build()
+    except Exception as exc:                      # report, let the tests that need it fail loudly
+        print("WARNING: __graft_entry__.build() failed: %r" % (exc,))

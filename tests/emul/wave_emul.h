@@ -107,8 +107,8 @@ struct wemu_bid_proxy {
     operator unsigned() const { return wemu::st().block_idx.x; }
   } x;
 };
-static wemu_tid_proxy threadIdx;
-static wemu_bid_proxy blockIdx;
+[[maybe_unused]] static wemu_tid_proxy threadIdx;
+[[maybe_unused]] static wemu_bid_proxy blockIdx;
 
 inline void __syncthreads() { wemu::block_barrier(); }
 inline unsigned long long __ballot(bool p) {

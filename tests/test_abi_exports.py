@@ -1,0 +1,47 @@
+"""The C-ABI library loads and exports every entry point include/fpc_engine.h declares (no compute
+calls, no GPU needed), and the POD layouts match the header."""
+import ctypes as C
+import os
+import re
+
+import fpc_ffi
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(REPO, "include", "fpc_engine.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fpc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 25
+    lib = fpc_ffi.lib()                      # raises if the library is missing: no CPU fallback exists
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == set(fpc_ffi.EXPORTS)
+    assert lib.fpc_abi_version() == 2
+
+
+def test_pod_layouts():
+    assert C.sizeof(fpc_ffi.Board) == 288 and C.sizeof(fpc_ffi.Move) == 8
+    assert fpc_ffi.Board.pl.offset == 196 and fpc_ffi.Board.turn.offset == 196 + 64 + 12
+
+
+def test_static_helpers_need_no_device():
+    lib = fpc_ffi.lib()
+    assert lib.fpc_action_space_size(14) == 23520 and lib.fpc_num_action_channels(8) == 72
+    assert lib.fpc_is_legal_location(14, 3, 0, 0) == 0 and lib.fpc_is_legal_location(14, 3, 3, 0) == 1
+    f, t = C.c_int(), C.c_int()
+    assert lib.fpc_flat_to_move(8, 50, C.byref(f), C.byref(t)) == 0 and lib.fpc_move_flat_index(8, f.value, t.value) == 50
+
+
+def test_engine_creation_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        return
+    import pytest
+    with pytest.raises(RuntimeError, match="no HIP device|fpc_create failed"):
+        fpc_ffi.Engine(8, 2, max_games=1, max_sims=1)

@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -51,7 +52,7 @@ struct E16<1> {  // fp16
 };
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128;
-constexpr int FC_SPLITK = 4;   // 736 blocks at 14x14: fine-grained enough for the dispatcher to balance 256 CUs
+constexpr int FC_SPLITK = 4;   // K-splits of a long policy-Linear block; short blocks use 2x (see k_fc256)
 
 // byte offset of 16-B chunk j of tile row `row` (BK elements per row), XOR-swizzled so that the
 // 16-lane groups of a ds_read_b128 touch 16 distinct 16-B slots of the 256-B bank row
@@ -534,37 +535,55 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
 
 // ================================================================================================
 // k_fc256: the policy Linear (net.py:25: A -> A, 553 M weights at 14x14 = 1.1 GB in 16 bit) as a
-// weight-streaming GEMM for M = 256 rows.  HBM-bound: every weight byte is used once per forward.
+// weight-streaming GEMM for M = 256 rows: every weight byte is used once per forward.
 //   * W is stored by the exporter in MFMA FRAGMENT ORDER  [kstep16][n_tile32][lane 64][8 elems]
-//     (k-step major: all waves advance through K together, so what the chip reads at any moment is one
-//     contiguous region spread over every HBM channel instead of 1472 streams 1.4 MB apart):
+//     (k-step major: all waves advance through K together, so what the chip reads at any moment is a
+//     few contiguous regions spread over every HBM channel instead of 736 streams 1.4 MB apart):
 //     one v_mfma_f32_32x32x16 B-operand of a wave is one contiguous, perfectly coalesced 1-KiB read
 //     that goes straight from HBM into VGPRs -- the weights never touch LDS and are never shared
 //     between waves (each wave owns 32 output columns for all 256 rows).
-//   * Each wave keeps 4 stages (8 k-steps, 8 KiB) of its weight stream in flight.
-//   * Only the activations X[256][K] (12 MB, L2/MALL resident, re-read by every block) go through
-//     LDS (16 kB double buffer, swizzled), shared by the block's 4 waves.
-//   * grid = (Np/128) x SPLITK; partial sums [SPLITK][256][Np] f32 are combined with the bias in a
-//     fixed order by k_fc_reduce (deterministic, no atomics).
+//   * Only the activations X[256][K] (12 MB, L2 resident, re-read by every column group) go through
+//     LDS (2 x 32 KiB double buffer of BK = 64 stages, swizzled).  s_memtime stamps showed the waves of
+//     the 4-wave version spending 45 % of their time issuing those loads and waiting for them (the
+//     CU's one load path moved 2 bytes of X per byte of W), so a block is 8 waves = 256 columns: the
+//     X tile is fetched once per CU and stage, in full 128-byte lines, two stages ahead.
+//   * Work decomposition: column group j (256 columns) x K-split i.  Groups [0, G1) are cut into s1
+//     K-splits, the remaining groups into s2 = 2*s1 half-length ones, G1 chosen by the host so that
+//     the short blocks fill the tail of the last round (368 equal blocks on 256 CUs would idle 28 %).
+//     Block ids put the K-split in the low bits, so one XCD (id mod 8) only ever walks one K window
+//     of X and keeps it in its own L2.
+//   * Every block writes its f32 partial slab [Mtot][256]; k_fc_reduce adds a group's slabs and the
+//     bias in a fixed order (deterministic, no atomics).
 // ================================================================================================
 struct FcArgs {
   const uint16_t *X;      // [Mpad][Kp]
   const uint16_t *Wf;     // fragment order
-  float *part;            // [splitk][Mtot][Np]
-  int Kp, Np, ksteps, splitk, Mtot;
+  float *part;            // [slabs][Mtot][256]
+  int Kp, Np, ksteps, Mtot;
+  int G1, s1, s2;         // groups [0,G1): s1 splits; groups [G1, Np/256): s2 splits
 };
 
+constexpr int FC_THREADS = 512;
+
 template <int DT>
-__global__ void __launch_bounds__(256, 2) k_fc256(FcArgs g) {
-  __shared__ __attribute__((aligned(16))) unsigned char As[2][256 * 32 * 2];
+__global__ void __launch_bounds__(FC_THREADS, 1) k_fc256(FcArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned char As[2][256 * 64 * 2];   // 2 x 32 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ntile = blockIdx.x * 4 + wave;
-  const int KS = g.ksteps / g.splitk;             // k-steps (of 16) handled by this block; multiple of 8
-  const int ks0 = blockIdx.y * KS;
-  const int S = KS / 2;                           // stages of BK = 32
+  // block id -> (column group, K-split, slab)
+  const int nbig = g.G1 * g.s1;
+  const int id = blockIdx.x;
+  const bool big = id < nbig;
+  const int idr = big ? id : id - nbig;
+  const int sk = big ? g.s1 : g.s2;
+  const int group = big ? idr / sk : g.G1 + idr / sk;
+  const int split = idr % sk;
+  const int ntile = group * 8 + wave;
+  const int KS = g.ksteps / sk;                   // k-steps (of 16) handled by this block; multiple of 8
+  const int ks0 = split * KS;
+  const int S = KS / 4;                           // stages of BK = 64 (even, >= 4)
   const long wstride = (long)(g.Np / 32) * 64;    // u32x4 units between consecutive k-steps
   const u32x4_t *wsrc = reinterpret_cast<const u32x4_t *>(g.Wf) + ((long)ks0 * (g.Np / 32) + ntile) * 64 + lane;
-  const long mrow0 = (long)blockIdx.z * 256;
+  const long mrow0 = (long)blockIdx.y * 256;
 
   f32x16_t acc[8];
 #pragma unroll
@@ -572,93 +591,99 @@ __global__ void __launch_bounds__(256, 2) k_fc256(FcArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  u32x4_t wq[4][2];       // weight fragments of stages s .. s+3 (ring, statically indexed by unrolling)
-  u32x4_t ra[2][4];       // activation chunks two stages ahead (slot = stage parity)
+  u32x4_t wq[2][4];       // weight fragments of stages s, s+1 (slot = stage parity)
+  u32x4_t ra[4];          // the activation tile of the next stage on its way global -> LDS
   // NOTE: no conditionals around memory operations inside the steady-state loop -- a branch makes
-  // hipcc fall back to s_waitcnt vmcnt(0) at the join, which would serialise every stage on the full
-  // memory latency.  The host guarantees S % 4 == 0 and S >= 8; the last four stages run in a
-  // load-free epilogue copy of the step.
-#define FPC_ALOAD(SLOT_, S_)                                                                         \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
-    const int c_ = tid + 256 * i;                                                                    \
-    ra[SLOT_][i] = *reinterpret_cast<const u32x4_t *>(g.X + (mrow0 + (c_ >> 2)) * g.Kp + (long)(ks0 + 2 * (S_)) * 16 + (c_ & 3) * 8); \
-  }
-#define FPC_ASTORE(SLOT_, BUF_)                                                                      \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
-    const int c_ = tid + 256 * i;                                                                    \
-    *reinterpret_cast<u32x4_t *>(As[BUF_] + lds_off<32>(c_ >> 2, c_ & 3)) = ra[SLOT_][i];            \
-  }
+  // hipcc fall back to s_waitcnt vmcnt(0) at the join.  The last four stages run in a copy of the
+  // step without the loads that would run past the block's K range.
+  const uint16_t *xsrc = g.X + (mrow0 + (tid >> 3)) * g.Kp + (long)ks0 * 16 + (tid & 7) * 8;
+  const long xrow64 = 64L * g.Kp;                 // 512 threads cover 64 rows (8 lanes x 16 B = one 128-B line each) per pass
+#define FPC_ALOAD(S_)                                                                                \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+    ra[i] = *reinterpret_cast<const u32x4_t *>(xsrc + i * xrow64 + (long)(S_) * 64);
+#define FPC_ASTORE(BUF_)                                                                             \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+    *reinterpret_cast<u32x4_t *>(As[BUF_] + lds_off<64>((tid >> 3) + 64 * i, tid & 7)) = ra[i];
 #define FPC_WLOADQ(SLOT_, S_)                                                                        \
-  { wq[SLOT_][0] = wsrc[(long)(2 * (S_)) * wstride]; wq[SLOT_][1] = wsrc[(long)(2 * (S_) + 1) * wstride]; }
-  // 16 MFMAs of one stage; the 16 activation fragments are read from LDS four at a time, one group
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) wq[SLOT_][j] = wsrc[(long)(4 * (S_) + j) * wstride];
+  // 32 MFMAs of one stage; the activation fragments are read from LDS four at a time, two groups
   // ahead of the MFMAs that consume them (order pinned: hipcc otherwise serialises read->wait->mfma)
 #define FPC_RD4(DST, KS_, T0_)                                                                       \
   _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                      \
-    DST[q] = *reinterpret_cast<const u32x4_t *>(ab_ + lds_off<32>(((T0_) + q) * 32 + (lane & 31), (KS_) * 2 + (lane >> 5)));
+    DST[q] = *reinterpret_cast<const u32x4_t *>(ab_ + lds_off<64>(((T0_) + q) * 32 + (lane & 31), (KS_) * 2 + (lane >> 5)));
 #define FPC_MM4(SRC, W_, T0_)                                                                        \
   _Pragma("unroll") for (int q = 0; q < 4; ++q) acc[(T0_) + q] = E16<DT>::mfma(SRC[q], W_, acc[(T0_) + q]);
+#define FPC_SB __builtin_amdgcn_sched_barrier(0)
 #define FPC_FCMMA(S_, SLOT_)                                                                         \
   {                                                                                                  \
     const unsigned char *ab_ = As[(S_) & 1];                                                         \
     u32x4_t fp[4], fq[4];                                                                            \
-    FPC_RD4(fp, 0, 0); FPC_RD4(fq, 0, 4); __builtin_amdgcn_sched_barrier(0);                         \
-    FPC_MM4(fp, wq[SLOT_][0], 0); __builtin_amdgcn_sched_barrier(0); FPC_RD4(fp, 1, 0); __builtin_amdgcn_sched_barrier(0); \
-    FPC_MM4(fq, wq[SLOT_][0], 4); __builtin_amdgcn_sched_barrier(0); FPC_RD4(fq, 1, 4); __builtin_amdgcn_sched_barrier(0); \
-    FPC_MM4(fp, wq[SLOT_][1], 0); __builtin_amdgcn_sched_barrier(0);                                 \
-    FPC_MM4(fq, wq[SLOT_][1], 4); __builtin_amdgcn_sched_barrier(0);                                 \
+    FPC_RD4(fp, 0, 0); FPC_RD4(fq, 0, 4); FPC_SB;                                                    \
+    FPC_MM4(fp, wq[SLOT_][0], 0); FPC_SB; FPC_RD4(fp, 1, 0); FPC_SB;                                 \
+    FPC_MM4(fq, wq[SLOT_][0], 4); FPC_SB; FPC_RD4(fq, 1, 4); FPC_SB;                                 \
+    FPC_MM4(fp, wq[SLOT_][1], 0); FPC_SB; FPC_RD4(fp, 2, 0); FPC_SB;                                 \
+    FPC_MM4(fq, wq[SLOT_][1], 4); FPC_SB; FPC_RD4(fq, 2, 4); FPC_SB;                                 \
+    FPC_MM4(fp, wq[SLOT_][2], 0); FPC_SB; FPC_RD4(fp, 3, 0); FPC_SB;                                 \
+    FPC_MM4(fq, wq[SLOT_][2], 4); FPC_SB; FPC_RD4(fq, 3, 4); FPC_SB;                                 \
+    FPC_MM4(fp, wq[SLOT_][3], 0); FPC_SB;                                                            \
+    FPC_MM4(fq, wq[SLOT_][3], 4); FPC_SB;                                                            \
   }
 
-  FPC_WLOADQ(0, 0); FPC_WLOADQ(1, 1); FPC_WLOADQ(2, 2); FPC_WLOADQ(3, 3);
-  FPC_ALOAD(0, 0);
-  FPC_ASTORE(0, 0);
-  FPC_ALOAD(1, 1); FPC_ALOAD(0, 2);
+  FPC_ALOAD(0);
+  FPC_WLOADQ(0, 0); FPC_WLOADQ(1, 1);
+  FPC_ASTORE(0);
+  FPC_ALOAD(1);
   __syncthreads();
-  // stage s: MFMAs on As[s&1]; publish stage s+1 (slot (s+1)&1) to the other LDS buffer, then refill
-  // that slot with stage s+3 and the weight slot s%4 with stage s+4
-#define FPC_FCSTEP(S_, WSLOT_, ANEXT_)                                                               \
+  // stage s: MFMAs on As[s&1]; publish stage s+1 to the other LDS buffer, then request the
+  // activations and the weights of stage s+2 (activations first: loads retire in order, and the
+  // short L2 fetch must not queue behind the HBM one)
+#define FPC_FCSTEP(S_, P_)                                                                           \
   {                                                                                                  \
-    FPC_FCMMA(S_, WSLOT_);                                                                           \
-    FPC_WLOADQ(WSLOT_, (S_) + 4);                                                                    \
-    FPC_ASTORE(ANEXT_, ((S_) + 1) & 1);                                                              \
-    FPC_ALOAD(ANEXT_, (S_) + 3);                                                                     \
+    FPC_FCMMA(S_, P_);                                                                               \
+    FPC_ASTORE(1 - (P_));                                                                            \
+    FPC_ALOAD((S_) + 2);                                                                             \
+    FPC_SB;                                                                                          \
+    FPC_WLOADQ(P_, (S_) + 2);                                                                        \
     __syncthreads();                                                                                 \
   }
   int s = 0;
-  for (; s + 4 < S; s += 4) {
-    FPC_FCSTEP(s, 0, 1); FPC_FCSTEP(s + 1, 1, 0); FPC_FCSTEP(s + 2, 2, 1); FPC_FCSTEP(s + 3, 3, 0);
+  for (; s + 4 <= S; s += 2) {
+    FPC_FCSTEP(s, 0); FPC_FCSTEP(s + 1, 1);
   }
-  // last four stages: nothing left to fetch (slots already hold stages s+1, s+2; s+3 was requested)
-  FPC_FCMMA(s, 0); FPC_ASTORE(1, (s + 1) & 1); FPC_ALOAD(1, s + 3); __syncthreads();
-  FPC_FCMMA(s + 1, 1); FPC_ASTORE(0, (s + 2) & 1); __syncthreads();
-  FPC_FCMMA(s + 2, 2); FPC_ASTORE(1, (s + 3) & 1); __syncthreads();
-  FPC_FCMMA(s + 3, 3);
+  // last two stages (s = S-2): nothing left to fetch
+  FPC_FCMMA(s, 0); FPC_ASTORE(1); __syncthreads();
+  FPC_FCMMA(s + 1, 1);
 #undef FPC_FCSTEP
 #undef FPC_FCMMA
+#undef FPC_SB
 #undef FPC_RD4
 #undef FPC_MM4
 #undef FPC_ALOAD
 #undef FPC_ASTORE
 #undef FPC_WLOADQ
-  float *out = g.part + ((long)blockIdx.y * g.Mtot + mrow0) * g.Np;
-  const int n = ntile * 32 + (lane & 31);
+  const int slab = big ? id : nbig + idr;
+  float *out = g.part + ((long)slab * g.Mtot + mrow0) * 256;
+  const int n = wave * 32 + (lane & 31);
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      out[(long)m * g.Np + n] = acc[t][r];
+      out[(long)m * 256 + n] = acc[t][r];
     }
 }
 
-// logits[m][n] = bias[n] + part[0][m][n] + part[1][m][n] + ...   (fixed order)
-__global__ void __launch_bounds__(256) k_fc_reduce(const float *part, const float *bias, int splitk, int Mtot, int Np, int A, int n_rows,
-                                                   float *logits) {
+// logits[m][n] = bias[n] + slab[base][m][n%256] + slab[base+1][m][n%256] + ...   (fixed order)
+__global__ void __launch_bounds__(256) k_fc_reduce(const float *part, const float *bias, int G1, int s1, int s2, int Mtot, int A,
+                                                   int n_rows, float *logits) {
   const int q = blockIdx.x * 256 + threadIdx.x;         // float4 index within a row
   const int m = blockIdx.y;
   if (m >= n_rows || q * 4 >= A) return;
+  const int j = q >> 6;                                 // column group of 256
+  const int base = j < G1 ? j * s1 : G1 * s1 + (j - G1) * s2, cnt = j < G1 ? s1 : s2;
   float4 v = *reinterpret_cast<const float4 *>(bias + q * 4);
-  for (int k = 0; k < splitk; ++k) {
-    const float4 p = *reinterpret_cast<const float4 *>(part + ((long)k * Mtot + m) * Np + q * 4);
+  for (int k = 0; k < cnt; ++k) {
+    const float4 p = *reinterpret_cast<const float4 *>(part + ((long)(base + k) * Mtot + m) * 256 + (q & 63) * 4);
     v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
   }
   *reinterpret_cast<float4 *>(logits + (long)m * A + q * 4) = v;
@@ -733,7 +758,8 @@ struct NN {
   std::vector<ConvW> c1, c2;
   uint16_t *fcw = nullptr;
   float *fcb = nullptr, *vw = nullptr;
-  float *fc_part = nullptr;      // [FC_SPLITK][Gpad][Np] partial sums of k_fc256
+  float *fc_part = nullptr;      // [slabs][Gpad][256] partial sums of k_fc256 (sized for 2*FC_SPLITK slabs per group)
+  int fc_G1 = 0, fc_s2 = FC_SPLITK;   // work decomposition chosen at load time (plan_fc)
   uint16_t *towerW = nullptr;    // [2*nblocks][9][128][128] contiguous copy for k_tower (F == 128)
   float *towerB = nullptr;
   bool use_tower = false;
@@ -768,6 +794,33 @@ struct NN {
   float *logits() { return d_logits; }
   float *value() { return d_value; }
 
+  // Policy-Linear work decomposition (see k_fc256): how many column groups get FC_SPLITK long blocks,
+  // the rest getting twice as many half-length ones, so that the last round of blocks is full.
+  // Blocks are dispatched in id order, one per CU: simulate that and keep the shortest makespan.
+  void plan_fc() {
+    const int groups = Np / 256, ks = Kp / 16, mt = (Gmax + 255) / 256;
+    fc_s2 = (ks % (2 * FC_SPLITK * 8) == 0 && ks / (2 * FC_SPLITK) / 4 >= 4) ? 2 * FC_SPLITK : FC_SPLITK;
+    fc_G1 = groups;
+    if (fc_s2 == FC_SPLITK) return;
+    int cus = 256;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    long best = -1;
+    std::vector<long> fin(cus);
+    for (int g1 = groups; g1 >= 0; --g1) {
+      std::fill(fin.begin(), fin.end(), 0L);
+      for (int y = 0; y < mt; ++y)
+        for (int id = 0, nb = g1 * FC_SPLITK + (groups - g1) * fc_s2; id < nb; ++id) {
+          auto it = std::min_element(fin.begin(), fin.end());
+          *it += id < g1 * FC_SPLITK ? 2 : 1;
+        }
+      const long span = *std::max_element(fin.begin(), fin.end());
+      if (best < 0 || span < best) { best = span; fc_G1 = g1; }
+    }
+  }
+
   int load(const void *blob, uint64_t nbytes, std::string *err) {
     if (nbytes < sizeof(BlobHeader)) { *err = "weight blob too small"; return FPC_EWEIGHTS; }
     BlobHeader h;
@@ -775,8 +828,8 @@ struct NN {
     if (memcmp(h.magic, "FPCW", 4) || h.version != 2) { *err = "bad weight blob magic/version"; return FPC_EWEIGHTS; }
     if (h.R != dc.R || h.A_ch != dc.A_ch) { *err = "weight blob is for a different board size"; return FPC_EWEIGHTS; }
     if (h.dtype != dtype) { *err = "weight blob dtype differs from engine nn_dtype"; return FPC_EWEIGHTS; }
-    if (h.F % 64 || h.F < 64 || h.F > 512 || h.nblocks < 0 || h.Np % GEMM_BN || h.Kp % 64 || h.Np < dc.A || h.Kp < dc.A) {
-      *err = "unsupported network shape in weight blob (hidden must be a multiple of 64)";
+    if (h.F % 64 || h.F < 64 || h.F > 512 || h.nblocks < 0 || h.Np % 256 || h.Kp % 512 || h.Kp < 1024 || h.Np < dc.A || h.Kp < dc.A) {
+      *err = "unsupported network shape in weight blob (hidden must be a multiple of 64, Np of 256, Kp of 512)";
       return FPC_EWEIGHTS;
     }
     destroy();
@@ -816,7 +869,8 @@ struct NN {
     for (auto &a : act) if ((rc = dmalloc(&a, rows * F, err))) return rc;
     if ((rc = dmalloc(&yv, rows * 32, err))) return rc;
     if ((rc = dmalloc(&xfc, (size_t)Gpad * Kp, err))) return rc;
-    if ((rc = dmalloc(&fc_part, (size_t)FC_SPLITK * Gpad * Np, err))) return rc;
+    if ((rc = dmalloc(&fc_part, (size_t)2 * FC_SPLITK * Gpad * Np, err))) return rc;
+    plan_fc();
     if ((rc = dmalloc(&d_logits, (size_t)Gmax * dc.A, err))) return rc;
     if ((rc = dmalloc(&d_value, (size_t)Gmax, err))) return rc;
     use_tower = false;
@@ -904,12 +958,13 @@ struct NN {
     if (mark_fn) mark_fn(mark_ctx, 2);
     {
       FcArgs f{};
-      f.X = xfc; f.Wf = fcw; f.part = fc_part; f.Kp = Kp; f.Np = Np; f.ksteps = Kp / 16; f.splitk = FC_SPLITK; f.Mtot = Gpad;
+      f.X = xfc; f.Wf = fcw; f.part = fc_part; f.Kp = Kp; f.Np = Np; f.ksteps = Kp / 16; f.Mtot = Gpad;
+      f.G1 = fc_G1; f.s1 = FC_SPLITK; f.s2 = fc_s2;
       const int mtiles = (n + 255) / 256;
-      if ((Kp / 16 / FC_SPLITK / 2) % 4 != 0 || Kp / 16 / FC_SPLITK / 2 < 8) { *err = "policy Linear K does not fit the FC pipeline (K/64 must be a multiple of 4)"; return FPC_EWEIGHTS; }
-      hipLaunchKernelGGL((k_fc256<DT>), dim3(Np / 128, FC_SPLITK, mtiles), dim3(256), 0, stream, f);
+      const int blocks = fc_G1 * FC_SPLITK + (Np / 256 - fc_G1) * fc_s2;
+      hipLaunchKernelGGL((k_fc256<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), 0, stream, f);
       hipLaunchKernelGGL(k_fc_reduce, dim3((dc.A / 4 + 255) / 256, n), dim3(256), 0, stream, (const float *)fc_part, (const float *)fcb,
-                         FC_SPLITK, Gpad, Np, dc.A, n, logits_out);
+                         fc_G1, FC_SPLITK, fc_s2, Gpad, dc.A, n, logits_out);
       const hipError_t le = hipGetLastError();
       if (le != hipSuccess) { *err = std::string("k_fc256 launch failed: ") + hipGetErrorString(le); return FPC_ENODEVICE; }
     }

@@ -46,7 +46,7 @@ def export_weights(model, dtype=0):
     RR = A // A_ch
     R = int(round(RR ** 0.5))
     assert R * R == RR and fc.weight.shape[1] == A
-    Np = (A + 127) // 128 * 128
+    Np = (A + 255) // 256 * 256          # k_fc256 blocks own 256 columns
     Kp = (A + 511) // 512 * 512      # k_fc256: K/16 k-steps, split-K 4, 2 per stage, 4 stages per unrolled iteration
     secs = []
     w, b = _fold(model.startBlock[0], model.startBlock[1])

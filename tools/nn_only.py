@@ -15,7 +15,11 @@ eng = fpc_ffi.Engine(R, 3, max_games=G, max_sims=8)
 eng.load_weights(weights.export_weights(m, 0))
 x = (torch.rand(G, 24, R, R) < 0.1).float().cuda()
 lg = torch.empty(G, eng.A, device="cuda"); va = torch.empty(G, device="cuda")
+import time
+eng.nn_forward(x.data_ptr(), G, lg.data_ptr(), va.data_ptr())
 torch.cuda.synchronize()
+t0 = time.perf_counter()
 for _ in range(iters):
     eng.nn_forward(x.data_ptr(), G, lg.data_ptr(), va.data_ptr())
-print("done", float(lg.abs().mean()))
+torch.cuda.synchronize()
+print("done", float(lg.abs().mean()), "ms/forward %.4f" % ((time.perf_counter() - t0) / iters * 1e3))

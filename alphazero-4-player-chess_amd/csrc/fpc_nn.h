@@ -31,6 +31,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 template <int DT>
 struct E16;
@@ -38,6 +40,7 @@ template <>
 struct E16<0> {  // bf16
   static __device__ __forceinline__ uint16_t from_f32(float f) { __bf16 h = (__bf16)f; return __builtin_bit_cast(uint16_t, h); }
   static __device__ __forceinline__ float to_f32(uint16_t u) { return __builtin_bit_cast(float, (uint32_t)u << 16); }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)from_f32(lo) | ((uint32_t)from_f32(hi) << 16); }
   static __device__ __forceinline__ f32x16_t mfma(u32x4_t a, u32x4_t b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
   }
@@ -46,6 +49,7 @@ template <>
 struct E16<1> {  // fp16
   static __device__ __forceinline__ uint16_t from_f32(float f) { _Float16 h = (_Float16)f; return __builtin_bit_cast(uint16_t, h); }
   static __device__ __forceinline__ float to_f32(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)from_f32(lo) | ((uint32_t)from_f32(hi) << 16); }
   static __device__ __forceinline__ f32x16_t mfma(u32x4_t a, u32x4_t b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
@@ -273,6 +277,17 @@ struct TowerArgs {
   int L, P, R, PP, gpb, n_games, heads, Kp, A_ch;
 };
 
+// Diagnostic build only (-DFPC_EXP_STAMP, tools/stamps.py): s_memtime stamps that tell where a wave's
+// cycles go.  No stamp executes in the product build.
+#ifdef FPC_EXP_STAMP
+__device__ unsigned long long g_stamp_dbg[8 * 64];
+#define FPC_STAMP(V_) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V_) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define FPC_STAMP_ACC(SUM_, A_, B_) SUM_ += (B_) - (A_);
+#else
+#define FPC_STAMP(V_) {}
+#define FPC_STAMP_ACC(SUM_, A_, B_) {}
+#endif
+
 constexpr int TOWER_F = 128, TOWER_THREADS = 512;
 constexpr int TOWER_IMG = 256 * TOWER_F * 2;            // 65536
 constexpr int TOWER_STAGE = 128 * 128 * 2;              // 32768: one tap
@@ -288,17 +303,17 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
   const long m0 = (long)blockIdx.x * rows_used;
   const int game0 = blockIdx.x * g.gpb;
 
-  // per-lane interior predicate of its 2 x 16 accumulator rows
-  unsigned rowmask[2] = {0u, 0u};
+  // The accumulators hold the TRANSPOSED tile (MFMA called as W x X^T): lane l owns grid position
+  // (l & 31) of each of its two 32-row tiles and, per accumulator register r, output channel
+  // (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the 32-channel tile -- four consecutive channels per register
+  // quad, so an epilogue packs them into one 8-byte LDS write and needs one row predicate per tile.
+  bool rowin[2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int gi = row / g.PP, pos = row % g.PP, pi = pos / g.P, pj = pos % g.P;
-      const bool in = row < rows_used && game0 + gi < g.n_games && pi >= 1 && pi <= g.R && pj >= 1 && pj <= g.R;
-      rowmask[a] |= (in ? 1u : 0u) << r;
-    }
+  for (int a = 0; a < 2; ++a) {
+    const int row = wm * 64 + a * 32 + (lane & 31);
+    const int gi = row / g.PP, pos = row % g.PP, pi = pos / g.P, pj = pos % g.P;
+    rowin[a] = row < rows_used && game0 + gi < g.n_games && pi >= 1 && pi <= g.R && pj >= 1 && pj <= g.R;
+  }
 
   // zero the image (borders / unused rows must read as zero for every layer)
   for (int c = tid; c < TOWER_IMG / 16; c += TOWER_THREADS) reinterpret_cast<u32x4_t *>(img)[c] = u32x4_t{0u, 0u, 0u, 0u};
@@ -315,7 +330,7 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
 #define FPC_ZERO_ACC() \
   _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
   FPC_ZERO_ACC();
-  uint32_t res[2][2][8];          // residual x_l, packed 16-bit pairs (r even | r odd << 16), accumulator layout
+  uint32_t res[2][2][8];          // residual x_l, packed 16-bit channel pairs in accumulator layout
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -324,45 +339,56 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
       for (int k = 0; k < 8; ++k) res[a][b][k] = 0u;
 
   // epilogue of one layer, from registers, IN PLACE into the image: v = acc + bias (+res); ReLU;
-  // 16-bit at interior rows; KEEP_RES also refreshes the residual registers.
-#define FPC_TOWER_EPI(ADD_RES, KEEP_RES)                                                             \
+  // 16-bit at interior rows; KEEP_RES also refreshes the residual registers.  BIAS_ points at the
+  // layer's 128 biases in LDS (published through a free weight-ring slot before the layer barrier).
+#define FPC_TOWER_EPI(ADD_RES, KEEP_RES, BIAS_)                                                      \
   {                                                                                                  \
-    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b) {    \
-      const f32x16_t accv = a == 0 ? (b == 0 ? acc00 : acc01) : (b == 0 ? acc10 : acc11);            \
-      const float bs = b == 0 ? bias0 : bias1;                                                       \
-      const int n_ = wn * 64 + b * 32 + (lane & 31);                                                 \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                               \
-        float v = accv[r] + bs;                                                                      \
-        const uint32_t pr = res[a][b][r >> 1];                                                       \
-        if (ADD_RES) v += E16<DT>::to_f32((uint16_t)((r & 1) ? (pr >> 16) : (pr & 0xffffu)));        \
-        v = v > 0.f ? v : 0.f;                                                                       \
-        const bool in_ = (rowmask[a] >> r) & 1u;                                                     \
-        const uint16_t h = in_ ? E16<DT>::from_f32(v) : (uint16_t)0;                                 \
-        if (KEEP_RES) res[a][b][r >> 1] = (r & 1) ? ((pr & 0xffffu) | ((uint32_t)h << 16)) : ((pr & 0xffff0000u) | h); \
-        if (in_) {                                                                                   \
-          const int row = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);               \
-          *reinterpret_cast<uint16_t *>(img + lds_off<TOWER_F>(row, n_ >> 3) + (n_ & 7) * 2) = h;    \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b) _Pragma("unroll") for (int q = 0; q < 4; ++q) {    \
+      const int c0_ = wn * 64 + b * 32 + 8 * q + 4 * (lane >> 5);                                    \
+      const f32x4_t bs_ = *reinterpret_cast<const f32x4_t *>((BIAS_) + c0_);                         \
+      _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                \
+        const f32x16_t accv = a == 0 ? (b == 0 ? acc00 : acc01) : (b == 0 ? acc10 : acc11);          \
+        float v0 = accv[4 * q] + bs_[0], v1 = accv[4 * q + 1] + bs_[1];                              \
+        float v2 = accv[4 * q + 2] + bs_[2], v3 = accv[4 * q + 3] + bs_[3];                          \
+        if (ADD_RES) {                                                                               \
+          const uint32_t p0 = res[a][b][2 * q], p1 = res[a][b][2 * q + 1];                           \
+          v0 += E16<DT>::to_f32((uint16_t)(p0 & 0xffffu)); v1 += E16<DT>::to_f32((uint16_t)(p0 >> 16)); \
+          v2 += E16<DT>::to_f32((uint16_t)(p1 & 0xffffu)); v3 += E16<DT>::to_f32((uint16_t)(p1 >> 16)); \
+        }                                                                                            \
+        v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;                                          \
+        v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;                                          \
+        const uint32_t h01 = E16<DT>::pack2(v0, v1), h23 = E16<DT>::pack2(v2, v3);                   \
+        if (KEEP_RES) { res[a][b][2 * q] = h01; res[a][b][2 * q + 1] = h23; }                        \
+        if (rowin[a]) {                                                                              \
+          const int row = wm * 64 + a * 32 + (lane & 31);                                            \
+          *reinterpret_cast<u32x2_t *>(img + lds_off<TOWER_F>(row, c0_ >> 3) + (c0_ & 7) * 2) = u32x2_t{h01, h23}; \
         }                                                                                            \
       }                                                                                              \
     }                                                                                                \
   }
 
   // value head from the accumulators (net.py:28-35): relu(conv + bias)[q][ch] . vw[q][ch], ch < 24
-#define FPC_VALUE_EPI()                                                                              \
-  if (wn == 0 && (lane & 31) < 24) {                                                                 \
+#define FPC_VALUE_EPI(BIAS_)                                                                         \
+  if (wn == 0) {                                                                                     \
     _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                  \
-      const f32x16_t accv = a == 0 ? acc00 : acc10;                                                  \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                               \
-        if ((rowmask[a] >> r) & 1u) {                                                                \
-          const int row = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);               \
-          const int gi = row / g.PP, pos = row % g.PP;                                               \
-          const int q = (pos / g.P - 1) * g.R + (pos % g.P - 1);                                     \
-          float v = accv[r] + bias0;                                                                 \
-          v = v > 0.f ? v : 0.f;                                                                     \
-          v = E16<DT>::to_f32(E16<DT>::from_f32(v));     /* same rounding point as the unfused path */ \
-          const float pv = v * g.vw[q * 32 + (lane & 31)];                                           \
-          if (gi == 0) vsum0 += pv; else vsum1 += pv;                                                \
+      if (rowin[a]) {                                                                                \
+        const f32x16_t accv = a == 0 ? acc00 : acc10;                                                \
+        const int row = wm * 64 + a * 32 + (lane & 31);                                              \
+        const int gi = row / g.PP, pos = row % g.PP;                                                 \
+        const int qp = (pos / g.P - 1) * g.R + (pos % g.P - 1);                                      \
+        float pv = 0.f;                                                                              \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) {          /* channels 8q + 4(l>>5) + i < 24 */ \
+          const int c0_ = 8 * q + 4 * (lane >> 5);                                                   \
+          const f32x4_t bs_ = *reinterpret_cast<const f32x4_t *>((BIAS_) + c0_);                     \
+          const f32x4_t w4_ = *reinterpret_cast<const f32x4_t *>(g.vw + qp * 32 + c0_);              \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+            float v = accv[4 * q + i] + bs_[i];                                                      \
+            v = v > 0.f ? v : 0.f;                                                                   \
+            v = E16<DT>::to_f32(E16<DT>::from_f32(v));   /* same rounding point as the unfused path */ \
+            pv += v * w4_[i];                                                                        \
+          }                                                                                          \
         }                                                                                            \
+        if (gi == 0) vsum0 += pv; else vsum1 += pv;                                                  \
       }                                                                                              \
     }                                                                                                \
   }
@@ -374,7 +400,7 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
 #define FPC_SSTORE(REG, SLOT_) *reinterpret_cast<u32x4_t *>(ring + (SLOT_) * TOWER_STAGE + lds_off<32>(tid >> 2, tid & 3)) = REG;
     FPC_SLOAD(w0, 0);
     FPC_SLOAD(w1, 1);
-    const float bias0 = g.bstem[wn * 64 + (lane & 31)], bias1 = g.bstem[wn * 64 + 32 + (lane & 31)];
+    const float bstem_ = g.bstem[tid & 127];
     FPC_SSTORE(w0, 0);
     __syncthreads();
 #define FPC_SSTEP(S_, REG_NEXT, REG_FREE)                                                            \
@@ -389,10 +415,11 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
         const u32x4_t fa1 = *reinterpret_cast<const u32x4_t *>(enc + lds_off<32>((arow_ + 32) & 255, j_));    \
         const u32x4_t fb0 = *reinterpret_cast<const u32x4_t *>(wb_ + lds_off<32>(wn * 64 + (lane & 31), j_));      \
         const u32x4_t fb1 = *reinterpret_cast<const u32x4_t *>(wb_ + lds_off<32>(wn * 64 + 32 + (lane & 31), j_)); \
-        acc00 = E16<DT>::mfma(fa0, fb0, acc00); acc01 = E16<DT>::mfma(fa0, fb1, acc01);              \
-        acc10 = E16<DT>::mfma(fa1, fb0, acc10); acc11 = E16<DT>::mfma(fa1, fb1, acc11);              \
+        acc00 = E16<DT>::mfma(fb0, fa0, acc00); acc01 = E16<DT>::mfma(fb1, fa0, acc01);              \
+        acc10 = E16<DT>::mfma(fb0, fa1, acc10); acc11 = E16<DT>::mfma(fb1, fa1, acc11);              \
       }                                                                                              \
       if (s_ + 1 < 9) FPC_SSTORE(REG_NEXT, (s_ + 1) & 1);                                            \
+      if (s_ == 8 && tid < 128) reinterpret_cast<float *>(ring + TOWER_STAGE)[tid] = bstem_;   /* slot 1 is free after stage 7 */ \
       __syncthreads();                                                                               \
     }
     FPC_SSTEP(0, w1, w0); FPC_SSTEP(1, w0, w1); FPC_SSTEP(2, w1, w0); FPC_SSTEP(3, w0, w1); FPC_SSTEP(4, w1, w0);
@@ -400,8 +427,9 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
 #undef FPC_SSTEP
 #undef FPC_SLOAD
 #undef FPC_SSTORE
-    FPC_TOWER_EPI(false, true);
+    FPC_TOWER_EPI(false, true, reinterpret_cast<const float *>(ring + TOWER_STAGE));
     FPC_ZERO_ACC();
+    __syncthreads();                  /* slot 1 (the stem's biases) is rewritten by the tower's second tap */
   }
 
   // ---------------- tower: L layers x 9 stages (one tap = [128 cout][128 cin] per stage) ----------
@@ -422,7 +450,7 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
       *reinterpret_cast<u32x4_t *>(ring + (SLOT_) * TOWER_STAGE + lds_off<TOWER_F>(row_, j_)) = REGS[i]; \
     }                                                                                                \
   }
-  float bias0 = 0.f, bias1 = 0.f;
+  float bcur = 0.f;                   // this thread's share of the current layer's 128 biases
   if (total > 0) {
     FPC_TLOAD(rb0, 0);
     if (total > 1) FPC_TLOAD(rb1, 1);
@@ -435,18 +463,19 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
   B0 = *reinterpret_cast<const u32x4_t *>(wb_ + lds_off<TOWER_F>(rb0_, (KS_) * 2 + jh_));            \
   B1 = *reinterpret_cast<const u32x4_t *>(wb_ + lds_off<TOWER_F>(rb1_, (KS_) * 2 + jh_));
 #define FPC_MMA(A0, A1, B0, B1)                                                                      \
-  if (mode_ != 1) {                                                                                  \
-    acc00 = E16<DT>::mfma(A0, B0, acc00); acc01 = E16<DT>::mfma(A0, B1, acc01);                      \
-    acc10 = E16<DT>::mfma(A1, B0, acc10); acc11 = E16<DT>::mfma(A1, B1, acc11);                      \
+  if (mode_ != 1) {       /* W x X^T: the accumulators hold the transposed tile */                   \
+    acc00 = E16<DT>::mfma(B0, A0, acc00); acc01 = E16<DT>::mfma(B1, A0, acc01);                      \
+    acc10 = E16<DT>::mfma(B0, A1, acc10); acc11 = E16<DT>::mfma(B1, A1, acc11);                      \
   } else if (wn == 0) {   /* value conv: only the 32 live output columns */                          \
-    acc00 = E16<DT>::mfma(A0, B0, acc00); acc10 = E16<DT>::mfma(A1, B0, acc10);                      \
+    acc00 = E16<DT>::mfma(B0, A0, acc00); acc10 = E16<DT>::mfma(B0, A1, acc10);                      \
   }
 #define FPC_TSTEP(G_, REGS_NEXT, REGS_FREE, MODE_)   /* MODE_ literal: 0 tower layer, 1 value conv, 2 policy conv */ \
   {                                                                                                  \
     const int g_ = (G_), l_ = g_ / 9, tap_ = g_ % 9;                                                 \
     constexpr int mode_ = (MODE_);                                                                   \
+    FPC_STAMP(ts0);                                                                                  \
     if (g_ + 2 < total) FPC_TLOAD(REGS_FREE, g_ + 2);                                                \
-    if (tap_ == 0) { bias0 = g.bt[l_ * 128 + wn * 64 + (lane & 31)]; bias1 = g.bt[l_ * 128 + wn * 64 + 32 + (lane & 31)]; } \
+    if (tap_ == 0) bcur = g.bt[l_ * 128 + (tid & 127)];                                              \
     const int arow_ = (tap_ / 3 - 1) * g.P + (tap_ % 3 - 1) + wm * 64 + (lane & 31);                 \
     const unsigned char *wb_ = ring + (g_ % 3) * TOWER_STAGE;                                        \
     /* fragment reads software-pipelined one k-step ahead of the MFMAs that consume them */         \
@@ -464,17 +493,30 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
     FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(7, qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); \
     FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0);                                  \
     FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0);                                  \
+    FPC_STAMP(ts1);                                                                                  \
     if (g_ + 1 < total) FPC_TSTORE(REGS_NEXT, (g_ + 1) % 3);                                         \
+    FPC_STAMP(ts2);                                                                                  \
     if (tap_ == 8) {                                                                                 \
+      /* ring slot (g+2)%3 is idle until the end of the next stage: it carries the layer's biases */ \
+      const float *bl_ = reinterpret_cast<const float *>(ring + ((g_ + 2) % 3) * TOWER_STAGE);       \
+      if (tid < 128) const_cast<float *>(bl_)[tid] = bcur;                                           \
       __syncthreads();               /* every wave is done reading this layer's input image */       \
-      if (mode_ == 1) { FPC_VALUE_EPI(); }                                                           \
-      else if (mode_ == 2) { FPC_TOWER_EPI(false, false); }   /* policy conv: ReLU rows in place */  \
-      else if (l_ & 1) { FPC_TOWER_EPI(true, true); } else { FPC_TOWER_EPI(false, false); }          \
+      FPC_STAMP(ts3);                                                                                \
+      if (mode_ == 1) { FPC_VALUE_EPI(bl_); }                                                        \
+      else if (mode_ == 2) { FPC_TOWER_EPI(false, false, bl_); }   /* policy conv: ReLU rows in place */  \
+      else if (l_ & 1) { FPC_TOWER_EPI(true, true, bl_); } else { FPC_TOWER_EPI(false, false, bl_); } \
       FPC_ZERO_ACC();                                                                                \
+      FPC_STAMP(ts4);                                                                                \
+      FPC_STAMP_ACC(tsum[3], ts2, ts3); FPC_STAMP_ACC(tsum[4], ts3, ts4);                            \
+      ts2 = ts4;                                                                                     \
     }                                                                                                \
     __syncthreads();                                                                                 \
+    FPC_STAMP(ts5);                                                                                  \
+    FPC_STAMP_ACC(tsum[0], ts0, ts1); FPC_STAMP_ACC(tsum[1], ts1, ts2 == ts4 ? ts1 : ts2); FPC_STAMP_ACC(tsum[2], ts2, ts5); \
   }
   const int tower_stages = g.L * 9;            // even
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 1, ts5 = 0, tsum[5] = {0, 0, 0, 0, 0};
+  (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)ts4; (void)ts5; (void)tsum;
   for (int gs = 0; gs < tower_stages; gs += 2) {
     FPC_TSTEP(gs, rb1, rb0, 0);
     FPC_TSTEP(gs + 1, rb0, rb1, 0);
@@ -497,6 +539,10 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
 #undef FPC_VALUE_EPI
 #undef FPC_ZERO_ACC
 
+#ifdef FPC_EXP_STAMP
+  if (lane == 0 && blockIdx.x % 37 == 0 && blockIdx.x / 37 < 4)
+    for (int i = 0; i < 5; ++i) g_stamp_dbg[((blockIdx.x / 37) * 8 + wave) * 8 + i] = tsum[i];
+#endif
   if (!g.heads) {
     // final x -> global grid (whole rows: borders are zero in the image)
     for (int c = tid; c < 256 * 16; c += TOWER_THREADS) {

@@ -644,69 +644,64 @@ __global__ void __launch_bounds__(FC_THREADS, 1) k_fc256(FcArgs g) {
   // step without the loads that would run past the block's K range.
   const uint16_t *xsrc = g.X + (mrow0 + (tid >> 3)) * g.Kp + (long)ks0 * 16 + (tid & 7) * 8;
   const long xrow64 = 64L * g.Kp;                 // 512 threads cover 64 rows (8 lanes x 16 B = one 128-B line each) per pass
-#define FPC_ALOAD(S_)                                                                                \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+#define FPC_ALOAD2(H_, S_)                                                                           \
+  _Pragma("unroll") for (int i = 2 * (H_); i < 2 * (H_) + 2; ++i)                                    \
     ra[i] = *reinterpret_cast<const u32x4_t *>(xsrc + i * xrow64 + (long)(S_) * 64);
-#define FPC_ASTORE(BUF_)                                                                             \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+#define FPC_ASTORE2(H_, BUF_)                                                                        \
+  _Pragma("unroll") for (int i = 2 * (H_); i < 2 * (H_) + 2; ++i)                                    \
     *reinterpret_cast<u32x4_t *>(As[BUF_] + lds_off<64>((tid >> 3) + 64 * i, tid & 7)) = ra[i];
-#define FPC_WLOADQ(SLOT_, S_)                                                                        \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j) wq[SLOT_][j] = wsrc[(long)(4 * (S_) + j) * wstride];
-  // 32 MFMAs of one stage; the activation fragments are read from LDS four at a time, two groups
-  // ahead of the MFMAs that consume them (order pinned: hipcc otherwise serialises read->wait->mfma)
+#define FPC_WLOAD1(SLOT_, J_, S_) wq[SLOT_][J_] = wsrc[(long)(4 * (S_) + (J_)) * wstride];
 #define FPC_RD4(DST, KS_, T0_)                                                                       \
   _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                      \
     DST[q] = *reinterpret_cast<const u32x4_t *>(ab_ + lds_off<64>(((T0_) + q) * 32 + (lane & 31), (KS_) * 2 + (lane >> 5)));
 #define FPC_MM4(SRC, W_, T0_)                                                                        \
   _Pragma("unroll") for (int q = 0; q < 4; ++q) acc[(T0_) + q] = E16<DT>::mfma(SRC[q], W_, acc[(T0_) + q]);
 #define FPC_SB __builtin_amdgcn_sched_barrier(0)
-#define FPC_FCMMA(S_, SLOT_)                                                                         \
+  // One stage = 32 MFMAs on As[s&1] in 8 groups of 4.  The activation fragments are read from LDS two
+  // groups ahead of the MFMAs that consume them, and the stage's memory traffic is spread between the
+  // groups instead of being issued in one burst after them: each weight fragment is re-requested for
+  // stage s+2 right after its last use (LW_), the staged activations of stage s+1 go to the other LDS
+  // buffer behind groups 4-5 (SX_) and their registers are re-requested for stage s+2 behind groups
+  // 6-7 (LX_).  LW_/SX_/LX_ are literals: no runtime conditionals around memory operations (a branch
+  // makes hipcc fall back to s_waitcnt vmcnt(0) at the join).
+#define FPC_FCSTEP(S_, P_, LW_, SX_, LX_)                                                            \
   {                                                                                                  \
     const unsigned char *ab_ = As[(S_) & 1];                                                         \
     u32x4_t fp[4], fq[4];                                                                            \
     FPC_RD4(fp, 0, 0); FPC_RD4(fq, 0, 4); FPC_SB;                                                    \
-    FPC_MM4(fp, wq[SLOT_][0], 0); FPC_SB; FPC_RD4(fp, 1, 0); FPC_SB;                                 \
-    FPC_MM4(fq, wq[SLOT_][0], 4); FPC_SB; FPC_RD4(fq, 1, 4); FPC_SB;                                 \
-    FPC_MM4(fp, wq[SLOT_][1], 0); FPC_SB; FPC_RD4(fp, 2, 0); FPC_SB;                                 \
-    FPC_MM4(fq, wq[SLOT_][1], 4); FPC_SB; FPC_RD4(fq, 2, 4); FPC_SB;                                 \
-    FPC_MM4(fp, wq[SLOT_][2], 0); FPC_SB; FPC_RD4(fp, 3, 0); FPC_SB;                                 \
-    FPC_MM4(fq, wq[SLOT_][2], 4); FPC_SB; FPC_RD4(fq, 3, 4); FPC_SB;                                 \
-    FPC_MM4(fp, wq[SLOT_][3], 0); FPC_SB;                                                            \
-    FPC_MM4(fq, wq[SLOT_][3], 4); FPC_SB;                                                            \
-  }
-
-  FPC_ALOAD(0);
-  FPC_WLOADQ(0, 0); FPC_WLOADQ(1, 1);
-  FPC_ASTORE(0);
-  FPC_ALOAD(1);
-  __syncthreads();
-  // stage s: MFMAs on As[s&1]; publish stage s+1 to the other LDS buffer, then request the
-  // activations and the weights of stage s+2 (activations first: loads retire in order, and the
-  // short L2 fetch must not queue behind the HBM one)
-#define FPC_FCSTEP(S_, P_)                                                                           \
-  {                                                                                                  \
-    FPC_FCMMA(S_, P_);                                                                               \
-    FPC_ASTORE(1 - (P_));                                                                            \
-    FPC_ALOAD((S_) + 2);                                                                             \
-    FPC_SB;                                                                                          \
-    FPC_WLOADQ(P_, (S_) + 2);                                                                        \
+    FPC_MM4(fp, wq[P_][0], 0); FPC_SB; FPC_RD4(fp, 1, 0); FPC_SB;                                    \
+    FPC_MM4(fq, wq[P_][0], 4); FPC_SB; FPC_RD4(fq, 1, 4); if (LW_) FPC_WLOAD1(P_, 0, (S_) + 2); FPC_SB; \
+    FPC_MM4(fp, wq[P_][1], 0); FPC_SB; FPC_RD4(fp, 2, 0); FPC_SB;                                    \
+    FPC_MM4(fq, wq[P_][1], 4); FPC_SB; FPC_RD4(fq, 2, 4); if (LW_) FPC_WLOAD1(P_, 1, (S_) + 2); FPC_SB; \
+    FPC_MM4(fp, wq[P_][2], 0); FPC_SB; FPC_RD4(fp, 3, 0); if (SX_) FPC_ASTORE2(0, 1 - (P_)); FPC_SB; \
+    FPC_MM4(fq, wq[P_][2], 4); FPC_SB; FPC_RD4(fq, 3, 4); if (LW_) FPC_WLOAD1(P_, 2, (S_) + 2);      \
+    if (SX_) FPC_ASTORE2(1, 1 - (P_)); FPC_SB;                                                       \
+    FPC_MM4(fp, wq[P_][3], 0); FPC_SB; if (LX_) FPC_ALOAD2(0, (S_) + 2); FPC_SB;                     \
+    FPC_MM4(fq, wq[P_][3], 4); FPC_SB; if (LW_) FPC_WLOAD1(P_, 3, (S_) + 2);                         \
+    if (LX_) FPC_ALOAD2(1, (S_) + 2); FPC_SB;                                                        \
     __syncthreads();                                                                                 \
   }
+
+  FPC_ALOAD2(0, 0); FPC_ALOAD2(1, 0);
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) { FPC_WLOAD1(0, j, 0); }
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) { FPC_WLOAD1(1, j, 1); }
+  FPC_ASTORE2(0, 0); FPC_ASTORE2(1, 0);
+  FPC_ALOAD2(0, 1); FPC_ALOAD2(1, 1);
+  __syncthreads();
   int s = 0;
   for (; s + 4 <= S; s += 2) {
-    FPC_FCSTEP(s, 0); FPC_FCSTEP(s + 1, 1);
+    FPC_FCSTEP(s, 0, 1, 1, 1); FPC_FCSTEP(s + 1, 1, 1, 1, 1);
   }
   // last two stages (s = S-2): nothing left to fetch
-  FPC_FCMMA(s, 0); FPC_ASTORE(1); __syncthreads();
-  FPC_FCMMA(s + 1, 1);
+  FPC_FCSTEP(s, 0, 0, 1, 0);
+  FPC_FCSTEP(s + 1, 1, 0, 0, 0);
 #undef FPC_FCSTEP
-#undef FPC_FCMMA
 #undef FPC_SB
 #undef FPC_RD4
 #undef FPC_MM4
-#undef FPC_ALOAD
-#undef FPC_ASTORE
-#undef FPC_WLOADQ
+#undef FPC_ALOAD2
+#undef FPC_ASTORE2
+#undef FPC_WLOAD1
   const int slab = big ? id : nbig + idr;
   float *out = g.part + ((long)slab * g.Mtot + mrow0) * 256;
   const int n = wave * 32 + (lane & 31);

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libfpc_engine.so")
+# FPC_ENGINE_LIB: developer knob for A/B timing of two builds of the same engine (tools/ab.sh)
+LIB_PATH = os.environ.get("FPC_ENGINE_LIB") or os.path.join(HERE, "csrc", "libfpc_engine.so")
 
 MAX_SQ, MAX_PL, NO_SQ, MAX_MOVES = 196, 16, 255, 256
 

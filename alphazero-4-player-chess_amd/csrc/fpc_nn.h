@@ -450,6 +450,13 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
       *reinterpret_cast<u32x4_t *>(ring + (SLOT_) * TOWER_STAGE + lds_off<TOWER_F>(row_, j_)) = REGS[i]; \
     }                                                                                                \
   }
+#define FPC_TSTORE2(REGS, SLOT_, H_)                                                                 \
+  {                                                                                                  \
+    _Pragma("unroll") for (int i = 2 * (H_); i < 2 * (H_) + 2; ++i) {                                \
+      const int c_ = tid + TOWER_THREADS * i, row_ = c_ >> 4, j_ = c_ & 15;                          \
+      *reinterpret_cast<u32x4_t *>(ring + (SLOT_) * TOWER_STAGE + lds_off<TOWER_F>(row_, j_)) = REGS[i]; \
+    }                                                                                                \
+  }
   float bcur = 0.f;                   // this thread's share of the current layer's 128 biases
   if (total > 0) {
     FPC_TLOAD(rb0, 0);
@@ -474,7 +481,6 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
     const int g_ = (G_), l_ = g_ / 9, tap_ = g_ % 9;                                                 \
     constexpr int mode_ = (MODE_);                                                                   \
     FPC_STAMP(ts0);                                                                                  \
-    if (g_ + 2 < total) FPC_TLOAD(REGS_FREE, g_ + 2);                                                \
     if (tap_ == 0) bcur = g.bt[l_ * 128 + (tid & 127)];                                              \
     const int arow_ = (tap_ / 3 - 1) * g.P + (tap_ % 3 - 1) + wm * 64 + (lane & 31);                 \
     const unsigned char *wb_ = ring + (g_ % 3) * TOWER_STAGE;                                        \
@@ -485,16 +491,23 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
     FPC_FRAG(0, pa0, pa1, pb0, pb1);                                                                 \
     FPC_FRAG(1, qa0, qa1, qb0, qb1);                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                               \
+    /* the stage's other memory traffic rides between the MFMA groups: the tap two stages ahead is  \
+       requested behind k-step 1, the next tap goes to its (idle) ring slot behind k-steps 4-5 */    \
     FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(2, pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); \
-    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(3, qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); \
+    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(3, qa0, qa1, qb0, qb1);  \
+    if (g_ + 2 < total) FPC_TLOAD(REGS_FREE, g_ + 2);                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
     FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(4, pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); \
     FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(5, qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); \
-    FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(6, pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); \
-    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(7, qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); \
+    FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(6, pa0, pa1, pb0, pb1);  \
+    if (g_ + 1 < total) FPC_TSTORE2(REGS_NEXT, (g_ + 1) % 3, 0);                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(7, qa0, qa1, qb0, qb1);  \
+    if (g_ + 1 < total) FPC_TSTORE2(REGS_NEXT, (g_ + 1) % 3, 1);                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
     FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0);                                  \
     FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0);                                  \
     FPC_STAMP(ts1);                                                                                  \
-    if (g_ + 1 < total) FPC_TSTORE(REGS_NEXT, (g_ + 1) % 3);                                         \
     FPC_STAMP(ts2);                                                                                  \
     if (tap_ == 8) {                                                                                 \
       /* ring slot (g+2)%3 is idle until the end of the next stage: it carries the layer's biases */ \
@@ -535,6 +548,7 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
 #undef FPC_MMA
 #undef FPC_TLOAD
 #undef FPC_TSTORE
+#undef FPC_TSTORE2
 #undef FPC_TOWER_EPI
 #undef FPC_VALUE_EPI
 #undef FPC_ZERO_ACC

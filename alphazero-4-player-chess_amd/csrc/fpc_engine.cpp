@@ -294,6 +294,7 @@ int fpc_create(const fpc_config *cfg, fpc_engine **out) {
   Tree &t = e->t;
   t.node_cap = 1 + cfg->max_sims * e->cfg.avg_children;
   t.board_cap = cfg->max_sims + 2;
+  t.path_cap = cfg->max_sims + 2;          // a descent visits at most one node per earlier expansion + the root
   const size_t nn = (size_t)Gm * t.node_cap;
   if ((r = dalloc(e, &t.N, nn)) || (r = dalloc(e, &t.W, nn)) || (r = dalloc(e, &t.P, nn)) || (r = dalloc(e, &t.mv, nn)) ||
       (r = dalloc(e, &t.parent, nn)) || (r = dalloc(e, &t.child0, nn)) || (r = dalloc(e, &t.nch, nn)) ||
@@ -301,6 +302,7 @@ int fpc_create(const fpc_config *cfg, fpc_engine **out) {
       (r = dalloc(e, &t.nnodes, Gm)) || (r = dalloc(e, &t.nboards, Gm)) || (r = dalloc(e, &t.alive, Gm)) ||
       (r = dalloc(e, &t.sims_done, Gm)) || (r = dalloc(e, &t.err, Gm)) || (r = dalloc(e, &t.leaf_node, Gm)) ||
       (r = dalloc(e, &t.leaf_turn, Gm)) || (r = dalloc(e, &t.nlegal, Gm)) ||
+      (r = dalloc(e, &t.path, (size_t)Gm * t.path_cap)) || (r = dalloc(e, &t.path_len, Gm)) ||
       (r = dalloc(e, &t.legal, (size_t)Gm * FPC_MAX_MOVES)) || (r = dalloc(e, &t.leaf_slot, Gm)) ||
       (r = dalloc(e, &e->d_enc_f32, (size_t)Gm * 24 * e->dc.RR)) || (r = dalloc(e, &e->d_roots, Gm)) ||
       (r = dalloc(e, &e->d_logtab, (size_t)cfg->max_sims + 16)))

@@ -48,6 +48,9 @@ struct Tree {
   int *leaf_turn;
   int *nlegal;
   uint16_t *legal;   // [G][FPC_MAX_MOVES] ascending unique flat indices of the leaf's legal moves
+  int *path;         // [G][path_cap] root..leaf node ids of this step's descent (k_select -> k_expand's backup)
+  int *path_len;
+  int path_cap;
 };
 
 // ---- LDS image of one wave --------------------------------------------------------------------
@@ -776,6 +779,20 @@ __device__ __forceinline__ void backprop_lane0(const Tree &t, size_t nb, int n, 
   }
 }
 
+// BackpropagateNodes (node.cpp:118-126) along the descent path k_select recorded: path[len-1] is the
+// leaf (+v), its parent gets -v, ... -- every node of the path is touched once, so the lanes of one
+// wave update them independently instead of one lane chasing parent pointers.
+__device__ __forceinline__ void backprop_path(const Tree &t, size_t nb, int g, float v) {
+  const int len = t.path_len[g];
+  const int *path = t.path + (size_t)g * t.path_cap;
+  for (int k = lane_id(); k < len; k += 64) {
+    const int node = path[k];
+    const float sv = ((len - 1 - k) & 1) ? -v : v;
+    t.W[nb + node] += (double)sv;
+    t.N[nb + node] += 1;
+  }
+}
+
 __global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double Cpuct, const double *logtab) {
   __shared__ WaveLds s;
   const int g = blockIdx.x;
@@ -789,9 +806,12 @@ __global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double C
   // ---- descent: SelectChild (node.cpp:49-78)
   //   ucb_i = W_i/N_i + C * sqrt( log(sqrt(N_parent)) / (1 + N_i) ) * P_i      (fp64, no contraction)
   //   strict '>' from -inf => lowest index wins ties, NaN never wins
-  int n = 0;
+  int n = 0, depth = 0;
   bool fail = false;
+  int *path = t.path + (size_t)g * t.path_cap;
   for (;;) {
+    if (lane == 0 && depth < t.path_cap) path[depth] = n;
+    ++depth;
     const int c0 = t.child0[nb + n];
     if (c0 < 0) break;
     const int nc = t.nch[nb + n];
@@ -869,7 +889,7 @@ __global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double C
   const int nl = s.nlegal;
   uint16_t *lg = t.legal + (size_t)g * FPC_MAX_MOVES;
   for (int k = lane; k < nl; k += 64) lg[k] = s.lsorted[k];
-  if (lane == 0) { t.leaf_node[g] = n; t.leaf_slot[g] = slot; t.leaf_turn[g] = s.b.turn; t.nlegal[g] = nl; }
+  if (lane == 0) { t.leaf_node[g] = n; t.leaf_slot[g] = slot; t.leaf_turn[g] = s.b.turn; t.nlegal[g] = nl; t.path_len[g] = depth; }
 }
 
 // ================================================================================================
@@ -916,6 +936,8 @@ __device__ __forceinline__ float fdiv_rn(float a, float b) {
 // order; the legal mass is a sequential ascending f32 sum.
 // ================================================================================================
 constexpr int EXPAND_THREADS = 256;   // 4 waves stream the logits row; wave 0 then finishes alone
+constexpr int EXPAND_MAXQ = 23;        // float4 groups per thread: ceil(A / 4 / 256) at A = 23520 (14x14)
+static_assert(EXPAND_MAXQ * EXPAND_THREADS * 4 >= (8 * 14 + 8) * 14 * 14, "k_expand keeps a whole logits row (board <= 14x14) in registers");
 __global__ void __launch_bounds__(EXPAND_THREADS) k_expand(DevCfg c, Tree t, int G, const float *logits, const float *value) {
   __shared__ WaveLds s;
   __shared__ float red_f[4];
@@ -929,13 +951,24 @@ __global__ void __launch_bounds__(EXPAND_THREADS) k_expand(DevCfg c, Tree t, int
   const size_t nb = (size_t)g * t.node_cap;
   const float *lg = logits + (size_t)g * c.A;
   const int A = c.A, ngroups = A / 4;        // A = (8R+8)*R*R is a multiple of 4 for even R
+  // The row is swept ONCE: every thread pulls all of its float4 groups (q % 256 == tid, at most
+  // EXPAND_MAXQ of them) into registers with the loads back to back -- one memory round trip instead
+  // of one per loop iteration, twice -- and both passes then run from registers.
+  float4 v[EXPAND_MAXQ];
+#pragma unroll
+  for (int i = 0; i < EXPAND_MAXQ; ++i) {
+    const int q = tid + i * EXPAND_THREADS;
+    v[i] = q < ngroups ? *reinterpret_cast<const float4 *>(lg + 4 * q) : float4{0.f, 0.f, 0.f, 0.f};
+  }
   // pass 1: max
   float m = -__builtin_inff();
   bool nan = false;
-  for (int q = tid; q < ngroups; q += EXPAND_THREADS) {
-    const float4 v = *reinterpret_cast<const float4 *>(lg + 4 * q);
-    nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
-    m = v.x > m ? v.x : m; m = v.y > m ? v.y : m; m = v.z > m ? v.z : m; m = v.w > m ? v.w : m;
+#pragma unroll
+  for (int i = 0; i < EXPAND_MAXQ; ++i) {
+    if (tid + i * EXPAND_THREADS < ngroups) {
+      nan |= (v[i].x != v[i].x) | (v[i].y != v[i].y) | (v[i].z != v[i].z) | (v[i].w != v[i].w);
+      m = v[i].x > m ? v[i].x : m; m = v[i].y > m ? v[i].y : m; m = v[i].z > m ? v[i].z : m; m = v[i].w > m ? v[i].w : m;
+    }
   }
   for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(m, off); m = o > m ? o : m; }
   const bool wnan = __ballot(nan) != 0ull;
@@ -948,12 +981,14 @@ __global__ void __launch_bounds__(EXPAND_THREADS) k_expand(DevCfg c, Tree t, int
   // pass 2: S.  Thread t owns the float4 groups q with q % 256 == t (ascending), each wave folds its
   // 64 partials with the xor butterfly, and the four wave sums are added in wave order.
   float part = 0.f;
-  for (int q = tid; q < ngroups; q += EXPAND_THREADS) {
-    const float4 v = *reinterpret_cast<const float4 *>(lg + 4 * q);
-    part = part + fpc_expf(v.x - m);
-    part = part + fpc_expf(v.y - m);
-    part = part + fpc_expf(v.z - m);
-    part = part + fpc_expf(v.w - m);
+#pragma unroll
+  for (int i = 0; i < EXPAND_MAXQ; ++i) {
+    if (tid + i * EXPAND_THREADS < ngroups) {
+      part = part + fpc_expf(v[i].x - m);
+      part = part + fpc_expf(v[i].y - m);
+      part = part + fpc_expf(v[i].z - m);
+      part = part + fpc_expf(v[i].w - m);
+    }
   }
   for (int off = 32; off >= 1; off >>= 1) part = part + __shfl_xor(part, off);
   if (lane == 0) red_f[wave] = part;
@@ -985,10 +1020,8 @@ __global__ void __launch_bounds__(EXPAND_THREADS) k_expand(DevCfg c, Tree t, int
   }
   const float T = s.scal_f;
   // BackpropagateNodes (mcts.py:78) before ExpandNodes (mcts.py:79)
-  if (lane == 0) {
-    backprop_lane0(t, nb, n, value[g]);
-    t.sims_done[g] += 1;
-  }
+  backprop_path(t, nb, g, value[g]);
+  if (lane == 0) t.sims_done[g] += 1;
   // children: ascending flat order, entries with prior == 0 dropped (torch.nonzero, mcts.py:84)
   const int base_node = t.nnodes[g];
   int created = 0;

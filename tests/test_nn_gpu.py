@@ -104,6 +104,32 @@ def test_resnet_forward_vs_torch_fp32(R, blocks, hidden, dtype, tol):
     eng.close()
 
 
+def test_resnet_forward_more_than_256_rows():
+    """300 positions = two 256-row tiles of the policy Linear (blockIdx.y, plan_fc with two passes of
+    blocks) and 150 tower blocks of two 8x8 games each; same bound as the single-tile cases."""
+    import torch
+    import weights
+    R, dtype = 8, 1
+    m = _model(R, 2, 128, seed=5)
+    eng = make_engine("gpu", R, INV_OF[R], max_games=300, max_sims=4, nn_dtype=dtype)
+    eng.load_weights(weights.export_weights(m, dtype))
+    boards = _positions(R, 300)
+    n = len(boards)
+    assert n > 256
+    enc = np.concatenate([eng.encode([b]) for b in boards])
+    with torch.no_grad():
+        ref_l, ref_v = m(torch.from_numpy(enc))
+    x = torch.from_numpy(enc).cuda()
+    lg = torch.empty(n, eng.A, device="cuda")
+    va = torch.empty(n, device="cuda")
+    torch.cuda.synchronize()
+    eng.nn_forward(x.data_ptr(), n, lg.data_ptr(), va.data_ptr())
+    el = (lg.cpu() - ref_l).abs().max().item()
+    ev = (va.cpu() - ref_v.squeeze(1)).abs().max().item()
+    assert el < 1e-3 and ev < 1e-3, (el, ev)
+    eng.close()
+
+
 @pytest.mark.parametrize("R,dtype", [(8, 0), (14, 1)])
 def test_fused_search_equals_stepwise(R, dtype):
     """fpc_search_run (encode->MFMA net->expand, no host round trip) must give exactly the visit

@@ -314,3 +314,82 @@ def case_castling_vs_oracle(backend, n_games=4, plies=40, sims=30, seed=21):
     _compare_search(res, oref, ("castling",))
     eng.close()
     return n_castle
+
+
+def case_arena_vs_oracle(backend, R, n_pairs=3, sims=24, max_len=30, seed=9, kinds=("hash", "ramp")):
+    """BASELINE configs[4] (arena eval, temperature 0): paired games between two evaluators through
+    arena.play_paired, against the same loop run on the ORACLE: every ply's legal child set, visit
+    counts and pick, every result and the adjudication must be identical."""
+    import random
+    import arena
+    g = gold(R)
+    INV = g["INV"]
+    st = g["start"]
+    rng = random.Random(seed)
+    starts_o = []
+    for _ in range(n_pairs):
+        b = orc.board_from_dict(R, st["turn"], st["dict"])
+        for _ply in range(rng.randrange(0, 24)):
+            lm = orc.legal_moves(b, R, INV)
+            flats = sorted(set(x[2] for x in lm))
+            nb, rc = orc.take_action(b, R, flats[rng.randrange(len(flats))])
+            assert rc == 0
+            if orc.game_result(orc.clone(nb), R, INV) != 0:
+                break
+            b = nb
+        starts_o.append(b)
+    ev_a, ev_b = evaluators.make(kinds[0], R), evaluators.make(kinds[1], R)
+    args = {"max_game_length": max_len}
+
+    # ---- the oracle's arena (same batching, same rules)
+    class OG:
+        pass
+    ogames = []
+    for k, b in enumerate(starts_o):
+        for a_team in (0, 1):
+            o = OG(); o.state = orc.clone(b); o.a_team = a_team; o.plies = []; o.result = 0; o.winner = None
+            ogames.append(o)
+    live = list(ogames)
+    for _ply in range(max_len):
+        if not live:
+            break
+        for ev, batch in ((ev_a, [o for o in live if (o.state.turn & 1) == o.a_team]),
+                          (ev_b, [o for o in live if (o.state.turn & 1) != o.a_team])):
+            if not batch:
+                continue
+            boards = [o.state for o in batch]
+            rc, res = orc.search(boards, R, INV, sims, 3.0, ev)
+            assert rc == 0
+            for o, r in zip(batch, res):
+                flats = [c[0] for c in r["children"]]; visits = [c[1] for c in r["children"]]
+                pick = arena.pick_argmax(flats, visits)
+                o.plies.append((int(o.state.turn), flats, visits, pick))
+                nb, rc2 = orc.take_action(r["board"], R, pick)      # the search leaves its list order in the root
+                assert rc2 == 0
+                o.state = nb
+                gr = orc.game_result(o.state, R, INV)
+                if gr != 0:
+                    o.result = gr
+                    o.winner = 0 if gr == 1 else (1 if gr == 2 else -1)
+        live = [o for o in live if o.result == 0]
+
+    # ---- the engine's arena
+    eng = make_engine(backend, R, INV, max_games=2 * n_pairs, max_sims=sims)
+    starts = [fpc_ffi.board_from_lists(R, b.turn, orc.lists_of(b)) for b in starts_o]
+    games = arena.play_paired(lambda pods: run_external_search(eng, backend, pods, sims, 3.0, ev_a),
+                              lambda pods: run_external_search(eng, backend, pods, sims, 3.0, ev_b), eng, starts, args)
+    assert len(games) == len(ogames)
+    n_plies = 0
+    for ga, o in zip(games, ogames):
+        assert len(ga.plies) == len(o.plies), (ga.gid, len(ga.plies), len(o.plies))
+        for (t, fl, vi, pk), (ot, ofl, ovi, opk) in zip(ga.plies, o.plies):
+            assert t == ot and [int(x) for x in fl] == ofl and [int(x) for x in vi] == ovi and pk == opk, (ga.gid, t)
+        assert ga.result == o.result
+        if o.result != 0:
+            assert ga.winner == o.winner
+        assert fpc_ffi.lists_of(ga.state) == orc.lists_of(o.state)
+        n_plies += len(ga.plies)
+    s = arena.summary(games)
+    assert s["games"] == 2 * n_pairs and abs(s["score_a"] + s["score_b"] - s["games"]) < 1e-9
+    eng.close()
+    return n_plies

@@ -44,3 +44,8 @@ def test_other_board_sizes_vs_oracle(R, INV):
 
 def test_castling_vs_oracle():
     assert ec.case_castling_vs_oracle("emul", n_games=2, plies=30, sims=16) > 0
+
+
+def test_arena_vs_oracle():
+    """configs[4]: paired temperature-0 arena games, engine vs oracle, every ply bit-exact"""
+    assert ec.case_arena_vs_oracle("emul", 8, n_pairs=2, sims=16, max_len=14) > 20

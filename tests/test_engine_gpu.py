@@ -48,3 +48,9 @@ def test_other_board_sizes_vs_oracle(R, INV):
 
 def test_castling_vs_oracle():
     assert ec.case_castling_vs_oracle("gpu", n_games=16, plies=80, sims=60) > 0
+
+
+@pytest.mark.parametrize("R,pairs,sims,max_len", [(8, 16, 60, 60), (14, 8, 48, 40)])
+def test_arena_vs_oracle(R, pairs, sims, max_len):
+    """configs[4]: paired temperature-0 arena games, engine vs oracle, every ply bit-exact"""
+    assert ec.case_arena_vs_oracle("gpu", R, n_pairs=pairs, sims=sims, max_len=max_len) > 100

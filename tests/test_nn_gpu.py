@@ -162,3 +162,31 @@ def test_fused_search_equals_stepwise(R, dtype):
         assert bytes(a) == bytes(b)
     assert int(res_a["sims_done"].sum()) > G * sims // 2
     eng.close()
+
+
+def test_arena_two_networks_temperature_zero():
+    """configs[4] with the internal MFMA nets: two engines (one per weight set) on one GPU play paired
+    games at temperature 0.  No sampling anywhere, so a second run must reproduce every visit count
+    and pick; every pick is one of the reported legal children."""
+    import arena
+    import weights
+    R, sims = 8, 32
+    ma, mb = _model(R, 2, 64, seed=11), _model(R, 2, 64, seed=12)
+    starts = _positions(R, 6)
+    traces = []
+    for _rep in range(2):
+        ea = make_engine("gpu", R, INV_OF[R], max_games=12, max_sims=sims, nn_dtype=0)
+        eb = make_engine("gpu", R, INV_OF[R], max_games=12, max_sims=sims, nn_dtype=0)
+        ea.load_weights(weights.export_weights(ma, 0))
+        eb.load_weights(weights.export_weights(mb, 0))
+        games = arena.play_paired(arena.nn_search_fn(ea, sims, 3.0), arena.nn_search_fn(eb, sims, 3.0), ea,
+                                  [fpc_ffi.clone_board(b) for b in starts], {"max_game_length": 16})
+        for g in games:
+            for _t, fl, _vi, pk in g.plies:
+                assert pk in [int(x) for x in fl]
+        s = arena.summary(games)
+        assert s["games"] == 12 and s["wins_a"] + s["wins_b"] + s["draws"] == 12
+        traces.append([[(t, [int(x) for x in fl], [int(x) for x in vi], pk) for t, fl, vi, pk in g.plies] + [g.winner]
+                       for g in games])
+        ea.close(); eb.close()
+    assert traces[0] == traces[1]

@@ -59,7 +59,12 @@ struct fpc_engine {
   bool timing = false;
   fpc_stats stats{};
   // asynchronous stage timing: events are only RECORDED on the stream during the search and read
-  // back in fpc_search_results, so enabling it does not serialise the pipeline
+  // back in fpc_search_results, so enabling it does not serialise the pipeline.  Five events per
+  // simulation step still cost 2.7 % of the step, so only every TIMING_PERIOD-th step carries them
+  // and its intervals are scaled by the period.
+  static constexpr int TIMING_PERIOD = 8;
+  uint64_t tstep = 0;
+  bool tsample = false;
   std::vector<hipEvent_t> evpool;
   std::vector<int> evtag;          // 0 step start, 1 tower start, 2 Linear start, 3 expand start, 4 step end
   size_t evused = 0;
@@ -169,7 +174,8 @@ struct LocHash {   // std::hash<chess::BoardLocation>, engine/board.h:229-237
 };
 
 void mark(fpc_engine *e, int tag) {
-  if (!e->timing) return;
+  if (tag == 0) e->tsample = e->timing && (e->tstep++ % fpc_engine::TIMING_PERIOD) == 0;
+  if (!e->tsample) return;
   if (e->evused == e->evpool.size()) {
     hipEvent_t ev = nullptr;
     if (hipEventCreate(&ev) != hipSuccess) return;
@@ -187,6 +193,7 @@ void resolve_marks(fpc_engine *e) {
     if (b != a + 1) continue;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e->evpool[i], e->evpool[i + 1]) != hipSuccess) continue;
+    ms *= (float)fpc_engine::TIMING_PERIOD;
     if (a == 0) e->stats.ms_select += ms; else if (a == 1) e->stats.ms_tower += ms; else if (a == 2) e->stats.ms_fc += ms; else e->stats.ms_expand += ms;
   }
   e->evused = 0;

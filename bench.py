@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--board", type=int, default=14)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-timing", action="store_true", help="developer knob: no HIP events between the stages (what do they cost?)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N>1 rehearsal on a single-GPU box: every rank uses device 0 (use with --backend gloo)")
@@ -167,7 +168,7 @@ def main():
     for _ in range(args.warmup):
         step(False)
     eng.stats_reset()
-    eng.set_timing(True)
+    eng.set_timing(not args.no_stage_timing)
     sync()
     t0 = time.perf_counter()
     total = 0

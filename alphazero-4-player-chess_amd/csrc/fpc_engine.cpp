@@ -466,9 +466,12 @@ int fpc_search_run(fpc_engine *e, int sims) {
   if (!e->nn.loaded) return fail(e, FPC_EWEIGHTS, "fpc_load_weights has not been called");
   for (int s = 0; s < sims; ++s) {
     launch_select(e);
-    FPC_LAUNCH(k_encode, e->G, 64, e->stream, e->dc, (const fpc_board *)e->t.boards, e->t.board_cap,
-               (const int *)e->t.leaf_slot, (const int *)e->t.leaf_turn, e->G, 1, (float *)nullptr, e->nn.input16(),
-               e->nn.one16(), -1);
+    if (e->nn.takes_boards())      // the tower megakernel encodes its games' leaves itself
+      e->nn.set_board_input((const fpc_board *)e->t.boards, e->t.board_cap, (const int *)e->t.leaf_slot, (const int *)e->t.leaf_turn);
+    else
+      FPC_LAUNCH(k_encode, e->G, 64, e->stream, e->dc, (const fpc_board *)e->t.boards, e->t.board_cap,
+                 (const int *)e->t.leaf_slot, (const int *)e->t.leaf_turn, e->G, 1, (float *)nullptr, e->nn.input16(),
+                 e->nn.one16(), -1);
     mark(e, 1);
     e->nn.mark_fn = [](void *ctx, int tag) { mark((fpc_engine *)ctx, tag); };
     e->nn.mark_ctx = e;

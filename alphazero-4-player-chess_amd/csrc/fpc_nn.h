@@ -275,6 +275,13 @@ struct TowerArgs {
   float *value;           // [n_games] = tanh(vb + sum relu(vconv) * vw)
   float vb;
   int L, P, R, PP, gpb, n_games, heads, Kp, A_ch;
+  // fused state encoding (boards != null; replaces in16): the block encodes its games' leaf positions
+  // itself -- GetEncodedStates (board.cpp:305-356) exactly as k_encode writes it, batch-wide rotation
+  // by the first live leaf's turn included (Q6) -- so the search needs no separate encode launch
+  const fpc_board *boards;
+  const int *leaf_slot, *leaf_turn;
+  int board_stride;
+  uint16_t one16;
 };
 
 // Diagnostic build only (-DFPC_EXP_STAMP, tools/stamps.py): s_memtime stamps that tell where a wave's
@@ -319,10 +326,41 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
   for (int c = tid; c < TOWER_IMG / 16; c += TOWER_THREADS) reinterpret_cast<u32x4_t *>(img)[c] = u32x4_t{0u, 0u, 0u, 0u};
   // encoded input (32 channels, 64-byte rows) -> ring slot 2, which the stem does not use for weights
   unsigned char *enc = ring + 2 * TOWER_STAGE;
+  // fused encode: the block's leaf boards (288 B each) are staged in ring slot 1 (idle until the
+  // stem's second stage) with the slot lookup and the batch rotation's lookups in flight together
+  int rot_k = 0;
+  fpc_board *lb = reinterpret_cast<fpc_board *>(ring + TOWER_STAGE);
+  int *lslot = reinterpret_cast<int *>(ring + TOWER_STAGE + 4 * sizeof(fpc_board));
+  if (g.boards) {
+    constexpr int WPB = (int)(sizeof(fpc_board) / 4);            // 72 words per board
+    const int bg = tid / WPB, bw = tid % WPB;
+    const bool mine = bg < g.gpb && game0 + bg < g.n_games;
+    const int slot = mine ? g.leaf_slot[game0 + bg] : -1;
+    rot_k = first_leaf_turn(g.leaf_slot, g.leaf_turn, g.n_games);
+    if (mine) {
+      if (slot >= 0) reinterpret_cast<uint32_t *>(lb + bg)[bw] =
+          reinterpret_cast<const uint32_t *>(g.boards + (size_t)(game0 + bg) * g.board_stride + slot)[bw];
+      if (bw == 0) lslot[bg] = slot;
+    }
+    __syncthreads();
+  }
   for (int c = tid; c < 256 * 4; c += TOWER_THREADS) {
     const int row = c >> 2, j = c & 3;
     u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
-    if (row < rows_used) v = *reinterpret_cast<const u32x4_t *>(g.in16 + (m0 + row) * 32 + j * 8);
+    if (!g.boards) {
+      if (row < rows_used) v = *reinterpret_cast<const u32x4_t *>(g.in16 + (m0 + row) * 32 + j * 8);
+    } else {
+      const int gi = row / g.PP, pos = row % g.PP, pi = pos / g.P, pj = pos % g.P;
+      if (row < rows_used && game0 + gi < g.n_games && pi >= 1 && pi <= g.R && pj >= 1 && pj <= g.R && lslot[gi] >= 0) {
+        const fpc_board *b = lb + gi;            // (a dead game's input stays all zero)
+        const uint8_t p = b->sq[rot90_src(g.R, rot_k, pi - 1, pj - 1)];
+        if (present(p)) {
+          int plane = 6 * ((colour_of(p) - b->turn) & 3) + type_of(p) - 1;   // Q7: -1 wraps to 23
+          if (plane < 0) plane += 24;
+          if ((plane >> 3) == j) v[(plane & 7) >> 1] = (plane & 1) ? (uint32_t)g.one16 << 16 : (uint32_t)g.one16;
+        }
+      }
+    }
     *reinterpret_cast<u32x4_t *>(enc + lds_off<32>(row, j)) = v;
   }
 
@@ -845,6 +883,12 @@ struct NN {
     loaded = false;
   }
   uint16_t *input16() { return in16 + (size_t)guard * 32; }
+  // the search's leaf positions as the next forward's input (tower path only; cleared by the forward)
+  const fpc_board *in_boards = nullptr;
+  const int *in_leaf_slot = nullptr, *in_leaf_turn = nullptr;
+  int in_board_stride = 0;
+  bool takes_boards() const { return use_tower; }
+  void set_board_input(const fpc_board *b, int stride, const int *slot, const int *turn) { in_boards = b; in_board_stride = stride; in_leaf_slot = slot; in_leaf_turn = turn; }
   uint16_t one16() const { return dtype ? 0x3C00 : 0x3F80; }
   float *logits() { return d_logits; }
   float *value() { return d_value; }
@@ -991,6 +1035,8 @@ struct NN {
     int cur = 0;
     if (use_tower) {
       TowerArgs t{};
+      t.boards = in_boards; t.leaf_slot = in_leaf_slot; t.leaf_turn = in_leaf_turn; t.board_stride = in_board_stride; t.one16 = one16();
+      in_boards = nullptr;
       t.in16 = in16 + (size_t)guard * 32; t.Wstem = stem.w; t.bstem = stem.b; t.Wt = towerW; t.bt = towerB;
       t.out = act[0] + (size_t)guard * F; t.L = 2 * nblocks; t.P = P; t.R = dc.R; t.PP = PP; t.gpb = 256 / PP; t.n_games = n;
       t.heads = 1; t.xfc = xfc; t.vw = vw; t.value = value_out; t.vb = vb; t.Kp = Kp; t.A_ch = dc.A_ch;

@@ -57,6 +57,7 @@ struct fpc_engine {
   int rc_cap = 0;
   // ---- stats
   bool timing = false;
+  int policy_mode = 0;            // FPC_POLICY_FULL / FPC_POLICY_LEGAL (fpc_search_run only)
   fpc_stats stats{};
   // asynchronous stage timing: events are only RECORDED on the stream during the search and read
   // back in fpc_search_results, so enabling it does not serialise the pipeline.  Five events per
@@ -203,7 +204,7 @@ void resolve_marks(fpc_engine *e) {
 
 extern "C" {
 
-int fpc_abi_version(void) { return 2; }
+int fpc_abi_version(void) { return 3; }
 
 const char *fpc_last_error(const fpc_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
@@ -475,11 +476,14 @@ int fpc_search_run(fpc_engine *e, int sims) {
     mark(e, 1);
     e->nn.mark_fn = [](void *ctx, int tag) { mark((fpc_engine *)ctx, tag); };
     e->nn.mark_ctx = e;
-    int r = e->nn.forward(e->G, &e->err);
+    int r = e->policy_mode == FPC_POLICY_LEGAL ? e->nn.forward_legal(e->G, e->t, &e->err) : e->nn.forward(e->G, &e->err);
     e->nn.mark_fn = nullptr;
     if (r) return r;
     mark(e, 3);
-    FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (const float *)e->nn.logits(), (const float *)e->nn.value());
+    if (e->policy_mode == FPC_POLICY_LEGAL)
+      FPC_LAUNCH(k_expand_legal, e->G, 64, e->stream, e->dc, e->t, e->G, (const float *)e->nn.legal_logits(), (const float *)e->nn.value());
+    else
+      FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (const float *)e->nn.logits(), (const float *)e->nn.value());
     mark(e, 4);
     e->stats.launches_select++; e->stats.launches_nn++; e->stats.launches_expand++;
   }
@@ -582,6 +586,12 @@ int fpc_stats_reset(fpc_engine *e) {
   e->stats = fpc_stats{};
   return 0;
 }
+int fpc_set_policy_mode(fpc_engine *e, int mode) {
+  if (!e || (mode != FPC_POLICY_FULL && mode != FPC_POLICY_LEGAL)) return fail(e, FPC_EINVAL, "bad policy mode");
+  e->policy_mode = mode;
+  return 0;
+}
+
 int fpc_set_timing(fpc_engine *e, int enabled) {
   if (!e) return FPC_EINVAL;
   e->timing = enabled != 0;

@@ -782,6 +782,112 @@ __global__ void __launch_bounds__(256) k_fc_reduce(const float *part, const floa
   *reinterpret_cast<float4 *>(logits + (long)m * A + q * 4) = v;
 }
 
+// ================================================================================================
+// LEGAL-ONLY policy head (opt-in, fpc_set_policy_mode(FPC_POLICY_LEGAL)).
+// The search consumes the policy Linear's output only at the leaf's legal moves (mask-multiply +
+// renormalise, mcts.py:74-76; the softmax denominator cancels), ~40 of 23 520 columns per game.
+// k_policy_gemv evaluates exactly those: for every (game, legal move) pair one wave streams the
+// move's weight row (Kp 16-bit values, contiguous in a row-major copy of the weights made once by
+// k_fc_unfrag) against the game's activation row staged in LDS -- 0.5 GB of weight rows per step at
+// 14x14 instead of the whole 1.1 GB matrix and its 283 GFLOP.  Pairs are dealt to the blocks in equal
+// shares (a game with 90 legal moves does not hold one CU three times longer than one with 30).
+// ================================================================================================
+template <int DT>
+__global__ void __launch_bounds__(256) k_fc_unfrag(const uint16_t *Wf, uint16_t *W2, int Np, int Kp) {
+  // one thread per 16-byte chunk of the row-major matrix: (n, k8) <- fragment order [ks][nt][lane][8]
+  const long c = (long)blockIdx.x * 256 + threadIdx.x;
+  const long chunks = (long)Np * (Kp / 8);
+  if (c >= chunks) return;
+  const int n = (int)(c / (Kp / 8)), k8 = (int)(c % (Kp / 8));
+  const int ks = k8 >> 1, h = k8 & 1, nt = n >> 5, n32 = n & 31;
+  const long src = (((long)ks * (Np / 32) + nt) * 64 + (h * 32 + n32)) * 8;
+  *reinterpret_cast<u32x4_t *>(W2 + (long)n * Kp + (long)k8 * 8) = *reinterpret_cast<const u32x4_t *>(Wf + src);
+}
+
+template <int DT>
+struct Dot16;
+template <>
+struct Dot16<0> {
+  static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 v2;
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false);
+  }
+};
+template <>
+struct Dot16<1> {
+  static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false);
+  }
+};
+
+constexpr int GEMV_THREADS = 256, GEMV_MAXG = 2048;
+
+template <int DT>
+__global__ void __launch_bounds__(GEMV_THREADS) k_policy_gemv(DevCfg c, Tree t, int G, const uint16_t *X, const uint16_t *W2,
+                                                              const float *bias, int Kp, float *ll) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char xs[];     // Kp * 2 bytes: one game's activation row
+  __shared__ int cum[GEMV_MAXG + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // pair offsets: cum[g] = number of (live game, legal move) pairs before game g
+  if (wave == 0) {
+    int run = 0;
+    for (int base = 0; base < G; base += 64) {
+      const int g = base + lane;
+      int v = (g < G && t.leaf_node[g] >= 0) ? t.nlegal[g] : 0;
+      int inc = v;
+      for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+      if (g < G) cum[g] = run + inc - v;
+      run += __shfl(inc, 63);
+    }
+    if (lane == 0) cum[G] = run;
+  }
+  __syncthreads();
+  const int total = cum[G];
+  const int p0 = (int)((long)total * blockIdx.x / gridDim.x), p1 = (int)((long)total * (blockIdx.x + 1) / gridDim.x);
+  if (p0 >= p1) return;
+  const int turn0 = first_leaf_turn(t.leaf_node, t.leaf_turn, G);
+  // first game of the range: the last g with cum[g] <= p0 among games that own pairs
+  int g = 0;
+  { int lo = 0, hi = G; while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cum[mid] <= p0) lo = mid; else hi = mid - 1; } g = lo; }
+  const int chunks = Kp / 8;                       // 16-byte chunks per row; a multiple of 64 (Kp % 512 == 0)
+  for (int p = p0; p < p1;) {
+    while (cum[g + 1] <= p) ++g;                   // skip games without pairs
+    const int pend = cum[g + 1] < p1 ? cum[g + 1] : p1;
+    __syncthreads();                               // the previous game's row is no longer being read
+    for (int q = tid; q < chunks; q += GEMV_THREADS)
+      reinterpret_cast<u32x4_t *>(xs)[q] = *reinterpret_cast<const u32x4_t *>(X + (long)g * Kp + (long)q * 8);
+    __syncthreads();
+    const uint16_t *legal = t.legal + (size_t)g * FPC_MAX_MOVES;
+    for (int pp = p + wave; pp < pend; pp += GEMV_THREADS / 64) {
+      const int j = pp - cum[g];
+      const int fl = legal[j];
+      const int plane = fl / c.RR, pos = fl % c.RR;
+      const int nsrc = plane * c.RR + rot90_src(c.R, -turn0, pos / c.R, pos % c.R);   // ParseActionspace's inverse rotation
+      const u32x4_t *wrow = reinterpret_cast<const u32x4_t *>(W2 + (long)nsrc * Kp) + lane;
+      const u32x4_t *xrow = reinterpret_cast<const u32x4_t *>(xs) + lane;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      for (int q0 = 0; q0 < chunks; q0 += 64 * 8) {          // 8 row chunks per lane in flight
+        u32x4_t w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = q0 + 64 * u < chunks ? wrow[q0 + 64 * u] : u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (q0 + 64 * u < chunks) {
+            const u32x4_t x = xrow[q0 + 64 * u];
+            a0 = Dot16<DT>::dot2(w[u][0], x[0], a0); a1 = Dot16<DT>::dot2(w[u][1], x[1], a1);
+            a2 = Dot16<DT>::dot2(w[u][2], x[2], a2); a3 = Dot16<DT>::dot2(w[u][3], x[3], a3);
+          }
+        }
+      }
+      float a = (a0 + a1) + (a2 + a3);
+      for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
+      if (lane == 0) ll[(size_t)g * FPC_MAX_MOVES + j] = bias[nsrc] + a;
+    }
+    p = pend;
+  }
+}
+
 // value head tail: Flatten + Linear(24*R*R -> 1) + Tanh (net.py:33-34) on the value conv output
 template <int DT>
 __global__ void __launch_bounds__(64) k_value_tail(const uint16_t *Y, const float *w, float bias, int P, int R, int PP,
@@ -881,6 +987,7 @@ struct NN {
     for (void *p : allocs) (void)hipFree(p);
     allocs.clear();
     loaded = false;
+    fcw2 = nullptr; d_ll = nullptr;
   }
   uint16_t *input16() { return in16 + (size_t)guard * 32; }
   // the search's leaf positions as the next forward's input (tower path only; cleared by the forward)
@@ -892,6 +999,9 @@ struct NN {
   uint16_t one16() const { return dtype ? 0x3C00 : 0x3F80; }
   float *logits() { return d_logits; }
   float *value() { return d_value; }
+  uint16_t *fcw2 = nullptr;      // row-major [Np][Kp] copy of the policy weights (legal-only head), made on first use
+  float *d_ll = nullptr;         // [Gmax][FPC_MAX_MOVES] logits of the leaves' legal moves
+  float *legal_logits() { return d_ll; }
 
   // Policy-Linear work decomposition (see k_fc256): how many column groups get FC_SPLITK long blocks,
   // the rest getting twice as many half-length ones, so that the last round of blocks is full.
@@ -1057,7 +1167,7 @@ struct NN {
       if ((rc = conv(vconv, act[cur], F, nullptr, yv, 32, 24, 0))) return rc;
     }
     if (mark_fn) mark_fn(mark_ctx, 2);
-    {
+    if (logits_out) {            // null: legal-only policy head, the caller runs k_policy_gemv instead
       FcArgs f{};
       f.X = xfc; f.Wf = fcw; f.part = fc_part; f.Kp = Kp; f.Np = Np; f.ksteps = Kp / 16; f.Mtot = Gpad;
       f.G1 = fc_G1; f.s1 = FC_SPLITK; f.s2 = fc_s2;
@@ -1077,6 +1187,38 @@ struct NN {
 
   int forward(int n, std::string *err) {
     return dtype ? forward_t<1>(n, d_logits, d_value, err) : forward_t<0>(n, d_logits, d_value, err);
+  }
+  // ---- legal-only policy head --------------------------------------------------------------
+  // one-time: row-major copy of the policy weights + the legal-logit buffer
+  int ensure_legal_head(std::string *err) {
+    if (fcw2) return 0;
+    if (Gmax > GEMV_MAXG) { *err = "legal-only policy head supports at most " + std::to_string(GEMV_MAXG) + " games per engine"; return FPC_EINVAL; }
+    int rc;
+    if ((rc = dmalloc(&fcw2, (size_t)Np * Kp, err)) || (rc = dmalloc(&d_ll, (size_t)Gmax * FPC_MAX_MOVES, err))) return rc;
+    const long chunks = (long)Np * (Kp / 8);
+    if (dtype) hipLaunchKernelGGL((k_fc_unfrag<1>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)fcw, fcw2, Np, Kp);
+    else hipLaunchKernelGGL((k_fc_unfrag<0>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)fcw, fcw2, Np, Kp);
+    if (hipGetLastError() != hipSuccess) { *err = "k_fc_unfrag launch failed"; return FPC_ENODEVICE; }
+    return 0;
+  }
+  // tower + heads only, then the policy Linear at the legal moves of the G leaves in `t`
+  int forward_legal(int n, const Tree &t, std::string *err) {
+    int rc = ensure_legal_head(err);
+    if (rc) return rc;
+    if ((rc = dtype ? forward_t<1>(n, nullptr, d_value, err) : forward_t<0>(n, nullptr, d_value, err))) return rc;
+    const size_t lds = (size_t)Kp * 2;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_gemv<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_gemv<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      attr = true;
+    }
+    if (lds > 64 * 1024) { *err = "legal-only policy head: activation row does not fit LDS"; return FPC_EINVAL; }
+    const int blocks = 768;      // 3 per CU (47 KiB of LDS each at 14x14); pairs are dealt out in equal shares
+    if (dtype) hipLaunchKernelGGL((k_policy_gemv<1>), dim3(blocks), dim3(GEMV_THREADS), lds, stream, dc, t, n, (const uint16_t *)xfc, (const uint16_t *)fcw2, (const float *)fcb, Kp, d_ll);
+    else hipLaunchKernelGGL((k_policy_gemv<0>), dim3(blocks), dim3(GEMV_THREADS), lds, stream, dc, t, n, (const uint16_t *)xfc, (const uint16_t *)fcw2, (const float *)fcb, Kp, d_ll);
+    if (hipGetLastError() != hipSuccess) { *err = "k_policy_gemv launch failed"; return FPC_ENODEVICE; }
+    return 0;
   }
   int forward_external(const float *enc, int n, float *logits_out, float *value_out, std::string *err) {
     if (dtype) hipLaunchKernelGGL((k_nchw_to_grid<1>), dim3(n), dim3(64), 0, stream, enc, n, dc.R, P, input16());

@@ -926,6 +926,52 @@ __device__ __forceinline__ float fdiv_rn(float a, float b) {
 #endif
 }
 
+// Shared end of both expand kernels (one wave): s.pri[0..nl) = unnormalised legal probabilities in
+// ascending flat order, s.lsorted the flat indices.  Legal mass (sequential ascending f32 sum),
+// policy error, BackpropagateNodes (mcts.py:78) before ExpandNodes (mcts.py:79), children appended.
+__device__ __forceinline__ void expand_finish(WaveLds &s, const Tree &t, int g, size_t nb, int n, int nl, bool nan, const float *value) {
+  const int lane = lane_id();
+  if (lane == 0) {
+    float T = 0.f;
+    for (int j = 0; j < nl; ++j) T = T + s.pri[j];
+    s.errbits = (nan || !(T > 0.f)) ? ERR_POLICY : 0;
+    s.scal_f = T;
+  }
+  __syncthreads();
+  if (s.errbits) {                          // the reference would expand all A indices and throw
+    if (lane == 0) { t.err[g] |= ERR_POLICY; t.alive[g] = 0; }
+    return;
+  }
+  const float T = s.scal_f;
+  // BackpropagateNodes (mcts.py:78) before ExpandNodes (mcts.py:79)
+  backprop_path(t, nb, g, value[g]);
+  if (lane == 0) t.sims_done[g] += 1;
+  // children: ascending flat order, entries with prior == 0 dropped (torch.nonzero, mcts.py:84)
+  const int base_node = t.nnodes[g];
+  int created = 0;
+  for (int b0 = 0; b0 < nl; b0 += 64) {
+    const int j = b0 + lane;
+    float pr = 0.f;
+    bool nz = false;
+    if (j < nl) { pr = fdiv_rn(s.pri[j], T); nz = pr != 0.f; }
+    const unsigned long long bal = __ballot(nz);
+    if (nz) {
+      const int k = base_node + created + __popcll(bal & ((1ull << lane) - 1ull));
+      if (k < t.node_cap) {
+        t.N[nb + k] = 1; t.W[nb + k] = 0.0; t.P[nb + k] = pr; t.mv[nb + k] = s.lsorted[j];
+        t.parent[nb + k] = n; t.child0[nb + k] = -1; t.nch[nb + k] = 0; t.bslot[nb + k] = -1;
+      }
+    }
+    created += __popcll(bal);
+  }
+  if (lane == 0) {
+    if (base_node + created > t.node_cap) { t.err[g] |= ERR_CAP_NODES; t.alive[g] = 0; }
+    else if (created > 0) {
+      t.child0[nb + n] = base_node; t.nch[nb + n] = (uint16_t)created; t.nnodes[g] = base_node + created;
+    }
+  }
+}
+
 // ================================================================================================
 // k_expand: mcts.py:67-89 for one leaf per wave.
 //   p = softmax(logits) over all A entries;  policy_abs[pl][r][c] = p[pl][rot90 by -turn0]  (Q6);
@@ -1007,45 +1053,42 @@ __global__ void __launch_bounds__(EXPAND_THREADS) k_expand(DevCfg c, Tree t, int
     s.lsorted[j] = (uint16_t)fl;
   }
   __syncthreads();
-  if (lane == 0) {
-    float T = 0.f;
-    for (int j = 0; j < nl; ++j) T = T + s.pri[j];
-    s.errbits = (nan || !(T > 0.f)) ? ERR_POLICY : 0;
-    s.scal_f = T;
+  expand_finish(s, t, g, nb, n, nl, nan, value);
+}
+
+
+// ================================================================================================
+// k_expand_legal: the same step for the LEGAL-ONLY policy head (opt-in, fpc_set_policy_mode): the
+// network evaluated the policy Linear only at the leaf's legal moves (k_policy_gemv, fpc_nn.h), so
+// ll[g][j] is the logit of legal move j (ascending flat order, already taken through the inverse
+// rotation).  prior_j = exp(l_j - max_legal) / sum_legal exp(l_k - max_legal): the full softmax's
+// denominator cancels in mask-multiply + renormalise (mcts.py:67-76), so this equals the reference's
+// priors up to f32 rounding -- except where a legal logit lies more than ~87 below the GLOBAL
+// maximum, which the full softmax would flush to zero (child dropped / policy error) and this form
+// cannot see.  One wave per game.
+// ================================================================================================
+__global__ void __launch_bounds__(64) k_expand_legal(DevCfg c, Tree t, int G, const float *ll, const float *value) {
+  __shared__ WaveLds s;
+  const int g = blockIdx.x;
+  if (g >= G) return;
+  const int lane = lane_id();
+  const int n = t.leaf_node[g];
+  if (n < 0) return;
+  const size_t nb = (size_t)g * t.node_cap;
+  const int nl = t.nlegal[g];
+  const uint16_t *legal = t.legal + (size_t)g * FPC_MAX_MOVES;
+  const float *lg = ll + (size_t)g * FPC_MAX_MOVES;
+  float m = -__builtin_inff();
+  bool nan = false;
+  for (int j = lane; j < nl; j += 64) { const float v = lg[j]; nan |= v != v; m = v > m ? v : m; }
+  for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(m, off); m = o > m ? o : m; }
+  nan = __ballot(nan) != 0ull;
+  for (int j = lane; j < nl; j += 64) {
+    s.pri[j] = m == -__builtin_inff() ? 0.f : fpc_expf(lg[j] - m);     // every legal logit -inf: mass 0 -> policy error
+    s.lsorted[j] = legal[j];
   }
   __syncthreads();
-  if (s.errbits) {                          // the reference would expand all A indices and throw
-    if (lane == 0) { t.err[g] |= ERR_POLICY; t.alive[g] = 0; }
-    return;
-  }
-  const float T = s.scal_f;
-  // BackpropagateNodes (mcts.py:78) before ExpandNodes (mcts.py:79)
-  backprop_path(t, nb, g, value[g]);
-  if (lane == 0) t.sims_done[g] += 1;
-  // children: ascending flat order, entries with prior == 0 dropped (torch.nonzero, mcts.py:84)
-  const int base_node = t.nnodes[g];
-  int created = 0;
-  for (int b0 = 0; b0 < nl; b0 += 64) {
-    const int j = b0 + lane;
-    float pr = 0.f;
-    bool nz = false;
-    if (j < nl) { pr = fdiv_rn(s.pri[j], T); nz = pr != 0.f; }
-    const unsigned long long bal = __ballot(nz);
-    if (nz) {
-      const int k = base_node + created + __popcll(bal & ((1ull << lane) - 1ull));
-      if (k < t.node_cap) {
-        t.N[nb + k] = 1; t.W[nb + k] = 0.0; t.P[nb + k] = pr; t.mv[nb + k] = s.lsorted[j];
-        t.parent[nb + k] = n; t.child0[nb + k] = -1; t.nch[nb + k] = 0; t.bslot[nb + k] = -1;
-      }
-    }
-    created += __popcll(bal);
-  }
-  if (lane == 0) {
-    if (base_node + created > t.node_cap) { t.err[g] |= ERR_CAP_NODES; t.alive[g] = 0; }
-    else if (created > 0) {
-      t.child0[nb + n] = base_node; t.nch[nb + n] = (uint16_t)created; t.nnodes[g] = base_node + created;
-    }
-  }
+  expand_finish(s, t, g, nb, n, nl, nan, value);
 }
 
 }  // namespace fpc

@@ -71,6 +71,7 @@ _SIGS = {
     "fpc_stats_get": (C.c_int, [C.c_void_p, P(Stats)]),
     "fpc_stats_reset": (C.c_int, [C.c_void_p]),
     "fpc_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "fpc_set_policy_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "fpc_stream": (C.c_void_p, [C.c_void_p]),
 }
 EXPORTS = sorted(_SIGS)
@@ -250,6 +251,11 @@ class Engine:
 
     def stats_reset(self):
         self.L.fpc_stats_reset(self.h)
+
+    def set_policy_mode(self, legal_only):
+        """fpc_search_run's policy head: False = the whole Linear + full softmax (reference arithmetic),
+        True = only the leaf's legal moves (same priors up to f32 rounding; include/fpc_engine.h)."""
+        self._chk(self.L.fpc_set_policy_mode(self.h, 1 if legal_only else 0))
 
     def set_timing(self, on):
         self.L.fpc_set_timing(self.h, 1 if on else 0)

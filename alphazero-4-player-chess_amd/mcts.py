@@ -38,6 +38,10 @@ class MCTS:
         self.args = args
         self.neural_net = neural_net
         self.nn_dtype = int(args.get("nn_dtype", 0)) if hasattr(args, "get") else 0
+        # "full" (default): whole policy Linear + full softmax, the reference's arithmetic op for op;
+        # "legal": opt-in legal-moves-only policy head (same priors up to f32 rounding, ~1.6x the
+        # simulations/s at 14x14; include/fpc_engine.h fpc_set_policy_mode)
+        self.policy_head = str(args.get("policy_head", "full")) if hasattr(args, "get") else "full"
         self._native = _is_resnet(neural_net)
 
     def sync_weights(self, eng):
@@ -62,6 +66,7 @@ class MCTS:
         eng.search_begin(pods, float(self.args["C"]))
         if self._native:
             self.sync_weights(eng)
+            eng.set_policy_mode(self.policy_head == "legal")
             eng.search_run(sims)
         else:
             self._search_external(eng, G, sims)

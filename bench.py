@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true", help="developer knob: no HIP events between the stages (what do they cost?)")
+    ap.add_argument("--no-alt-policy-head", action="store_true", help="skip the extra legal-only-policy-head measurement")
+    ap.add_argument("--policy-head", choices=["full", "legal"], default="full",
+                    help="full: whole policy Linear + full softmax (reference arithmetic, the headline); legal: opt-in legal-moves-only head")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N>1 rehearsal on a single-GPU box: every rank uses device 0 (use with --backend gloo)")
@@ -123,6 +126,7 @@ def main():
     torch.manual_seed(0)
     model = net.ResNet(Spec(R), args.blocks, args.hidden, "cpu").eval()
     eng = fpc_ffi.Engine(R, INV, max_games=G, max_sims=sims, device=local, nn_dtype=dt)
+    eng.set_policy_mode(args.policy_head == "legal")
     eng.load_weights(weights.export_weights(model, dt))
     turn, entries = positions.start_entries(R)
     start = fpc_ffi.board_from_dict(R, turn, entries)
@@ -188,6 +192,33 @@ def main():
         dist.all_reduce(ts, op=dist.ReduceOp.SUM)
         total = int(ts.item())
 
+    # Reported beside the headline, never as `value`: the same job with the opt-in legal-only policy head
+    # (fpc_set_policy_mode(FPC_POLICY_LEGAL)): the policy Linear is evaluated only at
+    # the leaves' legal moves.  Same priors up to f32 rounding; not the reference's op-for-op arithmetic.
+    alt = None
+    if args.policy_head == "full" and not args.no_alt_policy_head:
+        eng.set_policy_mode(True)
+        step(False)                       # builds the row-major weight copy once
+        sync()
+        a0 = time.perf_counter()
+        atotal = 0
+        for _ in range(3):
+            atotal += step(False)
+        sync()
+        aelapsed = time.perf_counter() - a0
+        eng.set_policy_mode(False)
+        if world > 1:
+            at = torch.tensor([aelapsed], device="cuda", dtype=torch.float64)
+            dist.all_reduce(at, op=dist.ReduceOp.MAX)
+            aelapsed = float(at.item())
+            as_ = torch.tensor([float(atotal)], device="cuda", dtype=torch.float64)
+            dist.all_reduce(as_, op=dist.ReduceOp.SUM)
+            atotal = int(as_.item())
+        alt = {"value": atotal / aelapsed, "unit": "sims/s", "steps": 3,
+               "note": "NOT the headline: policy Linear evaluated only at the leaves' legal moves (softmax denominator "
+                       "cancels in mask+renormalise); priors equal the full head's up to f32 rounding, visit counts identical in "
+                       "tests/test_nn_gpu.py::test_legal_only_policy_head_matches_full; opt-in via fpc_set_policy_mode"}
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -238,6 +269,9 @@ def main():
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(R, INV, model, args)
+    if alt is not None:
+        out["alt_policy_head_legal_only"] = alt
+    out["config"]["policy_head"] = args.policy_head
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -137,6 +137,15 @@ int fpc_search_select(fpc_engine *e, int *n_live, const float **enc_dev);
 int fpc_search_expand(fpc_engine *e, const float *logits_dev, const float *value_dev);
 /* all `sims` simulations with the internal network (weights from fpc_load_weights) */
 int fpc_search_run(fpc_engine *e, int sims);
+/* How fpc_search_run evaluates the policy head (net.py:22-26 + mcts.py:67-76):
+ *   FPC_POLICY_FULL  (default) the whole Linear A -> A, softmax over all A outputs, mask, renormalise
+ *                    -- the reference's arithmetic, op for op;
+ *   FPC_POLICY_LEGAL the Linear only at the leaf's legal moves (the softmax denominator cancels in
+ *                    mask + renormalise): the same priors up to f32 rounding, 1/50th of the weight
+ *                    traffic.  Not bit-comparable with FULL; deviates where a legal logit lies ~87
+ *                    below the global maximum (FULL flushes that child to zero).  Opt-in. */
+enum { FPC_POLICY_FULL = 0, FPC_POLICY_LEGAL = 1 };
+int fpc_set_policy_mode(fpc_engine *e, int mode);
 /* Root read-back == what alphazero.py:104-110 reads through Node.GetChildren /
  * GetMoveMade().GetFlatIndex() / GetVisitCount().  Arrays are [n_games][max_children].
  * roots_out (nullable): the root states with the piece-list order the search left them in. */

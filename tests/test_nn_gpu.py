@@ -190,3 +190,39 @@ def test_arena_two_networks_temperature_zero():
                        for g in games])
         ea.close(); eb.close()
     assert traces[0] == traces[1]
+
+
+@pytest.mark.parametrize("R,blocks,hidden,dtype", [(14, 2, 128, 0), (14, 2, 128, 1), (8, 2, 64, 0), (10, 2, 128, 1)])
+def test_legal_only_policy_head_matches_full(R, blocks, hidden, dtype):
+    """Opt-in FPC_POLICY_LEGAL: the policy Linear evaluated only at the leaves' legal moves
+    (k_policy_gemv) must give the priors of the full Linear + full softmax up to f32 rounding (the
+    softmax denominator cancels in mask + renormalise), the same value backups, and -- rounding
+    aside -- the same search: root priors after one simulation within 2e-5, and after a 40-simulation
+    search identical visit counts in (nearly) every game."""
+    import weights
+    m = _model(R, blocks, hidden, seed=21)
+    G, sims = 24, 40
+    boards = _positions(R, G)
+    out = {}
+    for mode in (False, True):
+        eng = make_engine("gpu", R, INV_OF[R], max_games=G, max_sims=sims, nn_dtype=dtype)
+        eng.load_weights(weights.export_weights(m, dtype))
+        eng.set_policy_mode(mode)
+        roots = [fpc_ffi.clone_board(b) for b in boards]
+        eng.search_begin(roots, 3.0)
+        eng.search_run(1)
+        r1 = eng.search_results(roots=roots)
+        roots = [fpc_ffi.clone_board(b) for b in boards]
+        eng.search_begin(roots, 3.0)
+        eng.search_run(sims)
+        r2 = eng.search_results(roots=roots)
+        out[mode] = (r1, r2)
+        eng.close()
+    (f1, f2), (l1, l2) = out[False], out[True]
+    assert (f1["n_children"] == l1["n_children"]).all() and (f1["flat"] == l1["flat"]).all()
+    dp = np.abs(f1["prior"] - l1["prior"]).max()
+    dw = np.abs(f1["w"] - l1["w"]).max()
+    same = sum(1 for g in range(G) if (f2["visits"][g] == l2["visits"][g]).all() and (f2["flat"][g] == l2["flat"][g]).all())
+    print("R=%d %s: max|dprior|=%.2e max|dW|=%.2e identical visit vectors %d/%d" % (R, "fp16" if dtype else "bf16", dp, dw, same, G))
+    assert dp < 2e-5 and dw == 0.0
+    assert same >= G - 2

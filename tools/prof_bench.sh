@@ -1,4 +1,4 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rm -rf gpurun_out/prof_tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_tmp -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof_tmp.log 2>&1; echo exit=$?; python3 - <<'PY'
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rm -rf gpurun_out/prof_tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_tmp -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-policy-head > gpurun_out/prof_tmp.log 2>&1; echo exit=$?; python3 - <<'PY'
 import csv, collections, glob
 f=glob.glob('gpurun_out/prof_tmp/*/*_kernel_trace.csv')[0]
 agg=collections.defaultdict(list)

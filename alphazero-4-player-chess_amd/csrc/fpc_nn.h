@@ -542,6 +542,12 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
     __builtin_amdgcn_sched_barrier(0);                                                               \
     FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(7, qa0, qa1, qb0, qb1);  \
     if (g_ + 1 < total) FPC_TSTORE2(REGS_NEXT, (g_ + 1) % 3, 1);                                     \
+    /* THE stage barrier sits here, right behind the ring stores, not at the stage's end: it       \
+       publishes the next tap (every wave stored before it) and proves that nobody still reads the   \
+       slot the NEXT stage will overwrite (a wave passing it has finished stage g-1).  A wave then   \
+       runs from the last MFMAs of this stage straight into the next stage's fragment reads, so the  \
+       two waves of a SIMD drift out of phase and hide each other's LDS latency. */                  \
+    __syncthreads();                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                               \
     FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0);                                  \
     FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0);                                  \
@@ -560,8 +566,8 @@ __global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
       FPC_STAMP(ts4);                                                                                \
       FPC_STAMP_ACC(tsum[3], ts2, ts3); FPC_STAMP_ACC(tsum[4], ts3, ts4);                            \
       ts2 = ts4;                                                                                     \
+      __syncthreads();               /* the next layer's input image is complete */                  \
     }                                                                                                \
-    __syncthreads();                                                                                 \
     FPC_STAMP(ts5);                                                                                  \
     FPC_STAMP_ACC(tsum[0], ts0, ts1); FPC_STAMP_ACC(tsum[1], ts1, ts2 == ts4 ? ts1 : ts2); FPC_STAMP_ACC(tsum[2], ts2, ts5); \
   }

@@ -265,7 +265,7 @@ def main():
                      "achieved": tree_bytes_per_sim(R) * G / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0,
                      "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": (tree_bytes_per_sim(R) * G / (tree_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if tree_ms > 0 else 0.0,
-                     "kernels": "k_select + k_encode + k_expand (latency-bound: one wavefront per game)"},
+                     "kernels": "k_select + k_expand (+ the leaf encode, done inside k_tower) -- latency-bound: one wavefront per game"},
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(R, INV, model, args)

@@ -21,11 +21,9 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 512)()
 print("rc", fpc_ffi.lib().fpc_debug_stamps(buf))
 a = np.array(buf[:], dtype=np.float64).reshape(64, 8)[:32, :5]
-names = ["frag reads + 32 mfma", "weight tap: wait + ds_write", "stage barrier", "layer barrier", "layer epilogue"]
+names = ["stage: frag reads + 32 mfma + ring traffic + stage barrier", "(unused)", "stage tail", "layer barrier", "layer epilogue"]
 def show(a, names):
     tot = a.mean(0).sum()
     for i, n in enumerate(names):
         print("%-28s %12.0f ticks/launch (%.1f%%)" % (n, a[:, i].mean(), 100 * a[:, i].mean() / tot))
 print("k_tower"); show(a, names)
-b = np.array(buf[:], dtype=np.float64).reshape(64, 8)[32:, :5]
-print("k_fc256 (long blocks)"); show(b, ["lds reads + W wait + 4 mfma", "28 mfma + reads", "X wait + ds_write", "issue X, W loads", "barrier"])

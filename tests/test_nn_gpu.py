@@ -2,6 +2,7 @@
 architecture (net.py mirrors /root/reference/src/py/net.py:6-63), and the fused device-resident
 search loop against the parity-checked step-wise path."""
 import ctypes as C
+import random
 
 import numpy as np
 import pytest
@@ -226,3 +227,47 @@ def test_legal_only_policy_head_matches_full(R, blocks, hidden, dtype):
     print("R=%d %s: max|dprior|=%.2e max|dW|=%.2e identical visit vectors %d/%d" % (R, "fp16" if dtype else "bf16", dp, dw, same, G))
     assert dp < 2e-5 and dw == 0.0
     assert same >= G - 2
+
+
+def test_full_size_search_invariants():
+    """BASELINE configs[1] at full size -- 256 concurrent games x 400 simulations, ResNet(10,128) bf16,
+    14x14 -- where the oracle cannot follow (the CPU net alone would take hours): size-independent
+    properties instead.  Roots are the start position advanced by 0-3 plies so the batch mixes turns
+    (quirk Q6).  For every game: root N = sims + 1 and sum N_child = #children + sims - 1 (quirk Q1),
+    the children are exactly the root's legal flat indices (ascending), priors are positive and sum
+    to 1, |W_child| <= N_child - 1; and the whole search is reproducible bit for bit."""
+    import weights
+    R, G, sims = 14, 256, 400
+    m = _model(R, 10, 128, seed=0)
+    eng = make_engine("gpu", R, INV_OF[R], max_games=G, max_sims=sims, nn_dtype=0)
+    eng.load_weights(weights.export_weights(m, 0))
+    g = gold(R)
+    st = g["start"]
+    base = fpc_ffi.board_from_dict(R, st["turn"], [tuple(e) for e in st["dict"]])
+    rng = random.Random(3)
+    boards = []
+    for i in range(G):
+        b = fpc_ffi.clone_board(base)
+        for _ in range(i % 4):
+            lm = eng.legal_moves([b])[0]
+            b = eng.take_action([b], [lm[rng.randrange(len(lm))][2]])[0]
+        boards.append(b)
+    runs = []
+    for _rep in range(2):
+        roots = [fpc_ffi.clone_board(b) for b in boards]
+        eng.search_begin(roots, 3.0)
+        eng.search_run(sims)
+        runs.append(eng.search_results(roots=roots))
+    r = runs[0]
+    legal = eng.legal_moves([fpc_ffi.clone_board(b) for b in boards])
+    for i in range(G):
+        n = int(r["n_children"][i])
+        assert int(r["sims_done"][i]) == sims and int(r["root_n"][i]) == sims + 1
+        assert int(r["visits"][i, :n].sum()) == n + sims - 1
+        assert [int(x) for x in r["flat"][i, :n]] == sorted(set(mv[2] for mv in legal[i]))
+        p = r["prior"][i, :n]
+        assert (p > 0).all() and abs(float(p.astype(np.float64).sum()) - 1.0) < 1e-5
+        assert (np.abs(r["w"][i, :n]) <= r["visits"][i, :n] - 1 + 1e-9).all()
+    for k in ("root_n", "n_children", "flat", "visits", "prior", "w"):
+        assert (runs[0][k] == runs[1][k]).all(), k
+    eng.close()

@@ -267,7 +267,7 @@ def main():
                      "frac": (tree_bytes_per_sim(R) * G / (tree_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if tree_ms > 0 else 0.0,
                      "kernels": "k_select + k_expand (+ the leaf encode, done inside k_tower) -- latency-bound: one wavefront per game"},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(R, INV, model, args)
     if alt is not None:
         out["alt_policy_head_legal_only"] = alt

@@ -47,7 +47,7 @@ def export_weights(model, dtype=0):
     R = int(round(RR ** 0.5))
     assert R * R == RR and fc.weight.shape[1] == A
     Np = (A + 255) // 256 * 256          # k_fc256 blocks own 256 columns
-    Kp = (A + 511) // 512 * 512      # k_fc256: K/16 k-steps, split-K 4, 2 per stage, 4 stages per unrolled iteration
+    Kp = (A + 511) // 512 * 512      # k_fc256: K/16 k-steps, split-K 4 (8 for the short blocks), 4 k-steps per stage, stages in pairs
     secs = []
     w, b = _fold(model.startBlock[0], model.startBlock[1])
     Fp = (F + 127) // 128 * 128

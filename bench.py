@@ -17,8 +17,8 @@ Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel group (the
 implicit-GEMM network forward) with HIP events recorded on the engine's own stream during the
 timed steps (every 8th simulation step carries the events; five per step cost 2.7 %); `cpu_baseline`
 times the CPU oracle (oracle/, test infrastructure) + PyTorch-CPU ResNet on a bounded sample of the
-same workload on this box's host cores (N = 1 only).  `value` is always measured with the full
-policy head (the reference's softmax -> mask -> renormalise arithmetic, op for op); after the timed
+same workload on this box's host cores (N = 1 only).  `value` is measured with the full
+policy head unless --policy-head legal is given (the reference's softmax -> mask -> renormalise arithmetic, op for op); after the timed
 region three more steps run with the opt-in legal-only policy head and are reported separately as
 `alt_policy_head_legal_only` -- never as `value`.
 """

@@ -271,3 +271,48 @@ def test_full_size_search_invariants():
     for k in ("root_n", "n_children", "flat", "visits", "prior", "w"):
         assert (runs[0][k] == runs[1][k]).all(), k
     eng.close()
+
+
+def test_native_search_with_dropped_roots_and_weight_reload():
+    """The fused on-device loop with games that leave the search early (quirk Q5: a terminal leaf drops
+    the root -- fewer simulations, the game's network input and pairs go empty) next to games that
+    run to the end, for both policy heads; then the same engine after loading OTHER weights must
+    equal a fresh engine with those weights (the legal-only head rebuilds its row-major weight copy)."""
+    import weights
+    R, sims = 8, 60
+    g = gold(R)
+    q5 = g["searches"][-1]["before"][0]                      # R rook / kings position of SURVEY section 4 (Q5)
+    boards = _positions(R, 6)
+    boards = boards[:3] + [fpc_ffi.board_from_lists(R, q5["turn"], q5["pl"])] + boards[3:] + [fpc_ffi.board_from_lists(R, q5["turn"], q5["pl"])]
+    G = len(boards)
+    ma, mb = _model(R, 2, 128, seed=31), _model(R, 2, 128, seed=32)
+
+    def run(eng):
+        roots = [fpc_ffi.clone_board(b) for b in boards]
+        eng.search_begin(roots, 3.0)
+        eng.search_run(sims)
+        return eng.search_results(roots=roots)
+
+    res = {}
+    for legal in (False, True):
+        eng = make_engine("gpu", R, INV_OF[R], max_games=G, max_sims=sims, nn_dtype=1)
+        eng.set_policy_mode(legal)
+        eng.load_weights(weights.export_weights(ma, 1))
+        ra = run(eng)
+        eng.load_weights(weights.export_weights(mb, 1))      # same engine, other weights
+        rb = run(eng)
+        eng.close()
+        fresh = make_engine("gpu", R, INV_OF[R], max_games=G, max_sims=sims, nn_dtype=1)
+        fresh.set_policy_mode(legal)
+        fresh.load_weights(weights.export_weights(mb, 1))
+        rf = run(fresh)
+        fresh.close()
+        for k in ("root_n", "n_children", "sims_done", "flat", "visits", "prior", "w"):
+            assert (rb[k] == rf[k]).all(), (legal, k)
+        assert not (ra["visits"] == rb["visits"]).all()       # the two networks do search differently
+        res[legal] = ra
+    for r in res.values():
+        sd = [int(x) for x in r["sims_done"]]
+        assert sd[3] < sims and sd[-1] < sims and sd[3] == sd[-1]          # the Q5 roots were dropped early
+        assert max(sd) == sims                                              # ... next to games that ran to the end
+    assert (res[False]["visits"] == res[True]["visits"]).all() and (res[False]["sims_done"] == res[True]["sims_done"]).all()

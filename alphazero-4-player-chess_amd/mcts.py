@@ -13,6 +13,7 @@ by the engine:
   Difference from the reference: the batch always has one slot per game (finished games are
   all-zero rows whose outputs are ignored) instead of only the live leaves.
 """
+import numpy as np
 import torch
 
 import alphazero_cpp as az
@@ -56,6 +57,17 @@ class MCTS:
             self.neural_net.train(was_training)
             eng.load_weights(blob)
             eng.weights_version = _param_version(self.neural_net)
+
+    def add_dirichlet_noise(self, policy, device):
+        """Counterpart of the reference's MCTS.add_dirichlet_noise (mcts.py:45-56): blends every row of
+        a [B, A] policy with one Dirichlet(alpha) sample over the whole action space,
+        (1 - eps) * policy + eps * noise, alpha/eps from args["dirichlet_alpha"/"dirichlet_epsilon"].
+        As in the reference it is provided but never called by search()."""
+        alpha, eps = float(self.args["dirichlet_alpha"]), float(self.args["dirichlet_epsilon"])
+        n_actions = int(self.gameType.action_space_size)
+        draw = np.random.dirichlet(np.full(n_actions, alpha), size=int(policy.shape[0]))
+        noise = torch.as_tensor(draw, dtype=torch.float32, device=device)
+        return policy * (1.0 - eps) + noise * eps
 
     @torch.no_grad()
     def search(self, games):

@@ -10,3 +10,23 @@ def test_reference_style_usage(R):
 
 def test_training_loop():
     assert dc.case_training_loop("emul") >= 1
+
+
+def test_add_dirichlet_noise_mirror():
+    """MCTS.add_dirichlet_noise (reference mcts.py:45-56, defined but unused there too): a convex blend
+    of each policy row with a Dirichlet sample over the whole action space."""
+    import numpy as np
+    import torch
+    dc.setup("emul", 8)
+    from four_player_chess_board import FourPlayerChess
+    from mcts import MCTS
+    A = FourPlayerChess.action_space_size
+    pol = torch.softmax(torch.arange(3 * A, dtype=torch.float32).reshape(3, A) % 13, dim=1)
+    m = MCTS(FourPlayerChess, lambda x: None, {"C": 3, "num_searches": 1, "dirichlet_alpha": 0.3, "dirichlet_epsilon": 0.25})
+    np.random.seed(0)
+    out = m.add_dirichlet_noise(pol, "cpu")
+    assert out.shape == pol.shape and out.dtype == torch.float32
+    assert torch.allclose(out.sum(1), torch.ones(3), atol=1e-5) and (out >= 0).all()
+    assert ((out - 0.75 * pol) >= -1e-7).all() and not torch.equal(out, pol)
+    m.args["dirichlet_epsilon"] = 0.0
+    assert torch.equal(m.add_dirichlet_noise(pol, "cpu"), pol)

@@ -51,10 +51,12 @@ struct fpc_engine {
   double *d_logtab = nullptr;
   float *d_enc_f32 = nullptr;     // [max_games,24,R,R]
   fpc_board *d_roots = nullptr;   // staging [max_games]
-  int *d_rc_i = nullptr;          // root-children gather
+  int *d_rc_i = nullptr;          // root-children gather: [2][rc_cap] flat | visits
   float *d_rc_f = nullptr;
   double *d_rc_d = nullptr;
-  int rc_cap = 0;
+  int *d_rc_meta = nullptr;       // [max_games][3]
+  size_t rc_cap = 0;
+  long sims_issued = 0;           // simulation steps since fpc_search_begin (bounded by max_sims: pools + log table)
   // ---- stats
   bool timing = false;
   int policy_mode = 0;            // FPC_POLICY_FULL / FPC_POLICY_LEGAL (fpc_search_run only)
@@ -85,6 +87,12 @@ int fail(fpc_engine *e, int code, const char *fmt, ...) {
   if (e) e->err = buf; else g_create_error = buf;
   return code;
 }
+
+// every entry point re-selects the handle's device: one process may hold engines on several GPUs
+#define USE_DEV(e)                                                                             \
+  do {                                                                                         \
+    if ((e) && hipSetDevice((e)->cfg.device) != hipSuccess) return fail(e, FPC_ENODEVICE, "hipSetDevice(%d) failed", (e)->cfg.device); \
+  } while (0)
 
 #define HIPCHK(e, call)                                                                        \
   do {                                                                                         \
@@ -285,7 +293,9 @@ int fpc_board_heuristic(const fpc_board *b, int team) {   // engine/board.cpp:12
 int fpc_create(const fpc_config *cfg, fpc_engine **out) {
   if (!cfg || !out) return fail(nullptr, FPC_EINVAL, "null argument");
   const int R = cfg->board_size, INV = cfg->invalid_area;
-  if (R < 6 || R > 14 || INV < 1 || 2 * INV >= R) return fail(nullptr, FPC_EINVAL, "unsupported board %dx%d/%d", R, R, INV);
+  // geometries the kernels implement: 8 generator slots per piece bound the knight loop (2*2*(INV-1) <= 8,
+  // engine/board.cpp:188) and the network kernels tile boards of 8..14 squares a side
+  if (R < 8 || R > 14 || INV < 1 || INV > 3 || 2 * INV >= R) return fail(nullptr, FPC_EINVAL, "unsupported board %dx%d/%d (supported: 8..14 a side, cut corners 1..3)", R, R, INV);
   if (cfg->max_games < 1 || cfg->max_sims < 1) return fail(nullptr, FPC_EINVAL, "max_games/max_sims must be positive");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device || cfg->device < 0)
@@ -313,7 +323,8 @@ int fpc_create(const fpc_config *cfg, fpc_engine **out) {
       (r = dalloc(e, &t.path, (size_t)Gm * t.path_cap)) || (r = dalloc(e, &t.path_len, Gm)) ||
       (r = dalloc(e, &t.legal, (size_t)Gm * FPC_MAX_MOVES)) || (r = dalloc(e, &t.leaf_slot, Gm)) ||
       (r = dalloc(e, &e->d_enc_f32, (size_t)Gm * 24 * e->dc.RR)) || (r = dalloc(e, &e->d_roots, Gm)) ||
-      (r = dalloc(e, &e->d_logtab, (size_t)cfg->max_sims + 16)))
+      (r = dalloc(e, &e->d_logtab, (size_t)cfg->max_sims + 16)) ||
+      (r = dalloc(e, &e->d_rc_meta, (size_t)Gm * 3)))
     return bail(r);
   {
     // log(sqrt(N_parent)) (node.cpp:53-54) tabulated with the HOST libm so that the device PUCT
@@ -334,6 +345,7 @@ int fpc_create(const fpc_config *cfg, fpc_engine **out) {
 
 void fpc_destroy(fpc_engine *e) {
   if (!e) return;
+  (void)hipSetDevice(e->cfg.device);
 #ifndef FPC_EMUL
   e->nn.destroy();
 #endif
@@ -346,6 +358,7 @@ void fpc_destroy(fpc_engine *e) {
 // ------------------------------------------------------------------------------------------------
 int fpc_boards_legal_moves(fpc_engine *e, fpc_board *boards, int n, fpc_move *moves, int *counts) {
   if (!e || !boards || !moves || !counts || n < 0) return fail(e, FPC_EINVAL, "bad argument");
+  USE_DEV(e);
   if (n == 0) return 0;
   int r;
   if ((r = check_boards(e, boards, n))) return r;
@@ -358,6 +371,7 @@ int fpc_boards_legal_moves(fpc_engine *e, fpc_board *boards, int n, fpc_move *mo
 
 int fpc_boards_game_result(fpc_engine *e, fpc_board *boards, int n, const int *player, int *results) {
   if (!e || !boards || !results || n < 0) return fail(e, FPC_EINVAL, "bad argument");
+  USE_DEV(e);
   if (n == 0) return 0;
   int r;
   if ((r = check_boards(e, boards, n))) return r;
@@ -369,6 +383,7 @@ int fpc_boards_game_result(fpc_engine *e, fpc_board *boards, int n, const int *p
 
 int fpc_boards_take_action(fpc_engine *e, const fpc_board *boards, const int *flat, int n, fpc_board *out) {
   if (!e || !boards || !flat || !out || n < 0) return fail(e, FPC_EINVAL, "bad argument");
+  USE_DEV(e);
   if (n == 0) return 0;
   int r;
   if ((r = check_boards(e, boards, n))) return r;
@@ -381,6 +396,7 @@ int fpc_boards_take_action(fpc_engine *e, const fpc_board *boards, const int *fl
 
 int fpc_boards_encode(fpc_engine *e, const fpc_board *boards, int n, float *out_host) {
   if (!e || !boards || !out_host || n < 0) return fail(e, FPC_EINVAL, "bad argument");
+  USE_DEV(e);
   if (n == 0) return 0;
   int r;
   if ((r = check_boards(e, boards, n))) return r;
@@ -396,6 +412,7 @@ int fpc_boards_encode(fpc_engine *e, const fpc_board *boards, int n, float *out_
 
 int fpc_boards_legal_mask(fpc_engine *e, fpc_board *boards, int n, float *out_host) {
   if (!e || !boards || !out_host || n < 0) return fail(e, FPC_EINVAL, "bad argument");
+  USE_DEV(e);
   if (n == 0) return 0;
   int r;
   if ((r = check_boards(e, boards, n))) return r;
@@ -410,6 +427,7 @@ int fpc_boards_legal_mask(fpc_engine *e, fpc_board *boards, int n, float *out_ho
 // ------------------------------------------------------------------------------------------------
 int fpc_search_begin(fpc_engine *e, const fpc_board *roots, int n_games, double c_puct) {
   if (!e || !roots || n_games < 1) return fail(e, FPC_EINVAL, "bad argument");
+  USE_DEV(e);
   if (n_games > e->cfg.max_games) return fail(e, FPC_EINVAL, "n_games %d > max_games %d", n_games, e->cfg.max_games);
   int r;
   if ((r = check_boards(e, roots, n_games))) return r;
@@ -419,6 +437,7 @@ int fpc_search_begin(fpc_engine *e, const fpc_board *roots, int n_games, double 
   FPC_LAUNCH(k_search_init, n_games, 64, e->stream, e->t, n_games, (const fpc_board *)e->d_roots);
   HIPCHK(e, hipGetLastError());
   e->searching = true;
+  e->sims_issued = 0;
   return 0;
 }
 
@@ -430,6 +449,9 @@ static int launch_select(fpc_engine *e) {
 
 int fpc_search_select(fpc_engine *e, int *n_live, const float **enc_dev) {
   if (!e || !e->searching) return fail(e, FPC_ESTATE, "fpc_search_begin has not been called");
+  USE_DEV(e);
+  if (e->sims_issued + 1 > e->cfg.max_sims) return fail(e, FPC_ECAPACITY, "more than max_sims = %d simulations since fpc_search_begin", e->cfg.max_sims);
+  e->sims_issued += 1;
   launch_select(e);
   FPC_LAUNCH(k_encode, e->G, 64, e->stream, e->dc, (const fpc_board *)e->t.boards, e->t.board_cap,
              (const int *)e->t.leaf_slot, (const int *)e->t.leaf_turn, e->G, 0, e->d_enc_f32, (uint16_t *)nullptr,
@@ -449,6 +471,7 @@ int fpc_search_select(fpc_engine *e, int *n_live, const float **enc_dev) {
 
 int fpc_search_expand(fpc_engine *e, const float *logits_dev, const float *value_dev) {
   if (!e || !e->searching) return fail(e, FPC_ESTATE, "fpc_search_begin has not been called");
+  USE_DEV(e);
   if (!logits_dev || !value_dev) return fail(e, FPC_EINVAL, "null logits/value");
   mark(e, 3);
   FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, logits_dev, value_dev);
@@ -460,7 +483,10 @@ int fpc_search_expand(fpc_engine *e, const float *logits_dev, const float *value
 
 int fpc_search_run(fpc_engine *e, int sims) {
   if (!e || !e->searching) return fail(e, FPC_ESTATE, "fpc_search_begin has not been called");
+  USE_DEV(e);
   if (sims < 0 || sims > e->cfg.max_sims) return fail(e, FPC_EINVAL, "sims %d > max_sims %d", sims, e->cfg.max_sims);
+  if (e->sims_issued + sims > e->cfg.max_sims) return fail(e, FPC_ECAPACITY, "more than max_sims = %d simulations since fpc_search_begin", e->cfg.max_sims);
+  e->sims_issued += sims;
 #ifdef FPC_EMUL
   return fail(e, FPC_EWEIGHTS, "the internal ResNet exists only in the gfx950 build");
 #else
@@ -496,15 +522,24 @@ int fpc_search_results(fpc_engine *e, fpc_board *roots_out, int *root_visits, in
                        int max_children, int *child_flat, int *child_visits, float *child_prior,
                        double *child_value_sum) {
   if (!e || !e->searching) return fail(e, FPC_ESTATE, "fpc_search_begin has not been called");
+  USE_DEV(e);
   if (max_children < 0) return fail(e, FPC_EINVAL, "bad max_children");
   const int G = e->G;
   int r;
   const size_t need = (size_t)G * std::max(max_children, 1);
-  if ((int)need > e->rc_cap) {
-    if ((r = dalloc(e, &e->d_rc_i, need * 2 + (size_t)G * 3)) || (r = dalloc(e, &e->d_rc_f, need)) || (r = dalloc(e, &e->d_rc_d, need))) return r;
-    e->rc_cap = (int)need;
+  if (need > e->rc_cap) {
+    auto drop = [&](auto **p) {
+      if (!*p) return;
+      (void)hipFree(*p);
+      e->allocs.erase(std::find(e->allocs.begin(), e->allocs.end(), (void *)*p));
+      *p = nullptr;
+    };
+    drop(&e->d_rc_i); drop(&e->d_rc_f); drop(&e->d_rc_d);
+    e->rc_cap = 0;
+    if ((r = dalloc(e, &e->d_rc_i, need * 2)) || (r = dalloc(e, &e->d_rc_f, need)) || (r = dalloc(e, &e->d_rc_d, need))) return r;
+    e->rc_cap = need;
   }
-  int *d_flat = e->d_rc_i, *d_vis = e->d_rc_i + need, *d_meta = e->d_rc_i + 2 * need;
+  int *d_flat = e->d_rc_i, *d_vis = e->d_rc_i + need, *d_meta = e->d_rc_meta;
   FPC_LAUNCH(k_root_children, G, 64, e->stream, e->t, G, max_children, d_flat, d_vis, e->d_rc_f, e->d_rc_d, d_meta, e->d_roots);
   HIPCHK(e, hipGetLastError());
   std::vector<int> meta((size_t)G * 3), errs(G);
@@ -531,6 +566,7 @@ int fpc_search_results(fpc_engine *e, fpc_board *roots_out, int *root_visits, in
 
 int fpc_search_grandchildren(fpc_engine *e, int game, int child_idx, int max_children, int *n, int *flat, int *visits) {
   if (!e || !e->searching || game < 0 || game >= e->G || !n) return fail(e, FPC_EINVAL, "bad argument");
+  USE_DEV(e);
   HIPCHK(e, hipStreamSynchronize(e->stream));
   const size_t nb = (size_t)game * e->t.node_cap;
   int c0 = -1;
@@ -556,6 +592,7 @@ int fpc_search_grandchildren(fpc_engine *e, int game, int child_idx, int max_chi
 // ------------------------------------------------------------------------------------------------
 int fpc_load_weights(fpc_engine *e, const void *blob, uint64_t nbytes) {
   if (!e || !blob) return fail(e, FPC_EINVAL, "bad argument");
+  USE_DEV(e);
 #ifdef FPC_EMUL
   (void)nbytes;
   return fail(e, FPC_EWEIGHTS, "the internal ResNet exists only in the gfx950 build");
@@ -566,6 +603,7 @@ int fpc_load_weights(fpc_engine *e, const void *blob, uint64_t nbytes) {
 
 int fpc_nn_forward(fpc_engine *e, const float *enc_dev, int n, float *logits_dev, float *value_dev) {
   if (!e || !enc_dev || !logits_dev || !value_dev) return fail(e, FPC_EINVAL, "bad argument");
+  USE_DEV(e);
 #ifdef FPC_EMUL
   (void)n;
   return fail(e, FPC_EWEIGHTS, "the internal ResNet exists only in the gfx950 build");

@@ -971,6 +971,8 @@ struct NN {
   void (*mark_fn)(void *, int) = nullptr;   // stage-timing hook of the engine (tag 2 = policy Linear starts)
   void *mark_ctx = nullptr;
   float vb = 0.f;
+  // dynamic-LDS opt-ins (hipFuncSetAttribute) already made for this engine's device
+  bool attr_conv[2][3] = {{false, false, false}, {false, false, false}}, attr_tower[2] = {false, false}, attr_gemv = false;
 
   template <class T>
   int dmalloc(T **p, size_t count, std::string *err) {
@@ -1089,7 +1091,7 @@ struct NN {
     if ((rc = dmalloc(&d_logits, (size_t)Gmax * dc.A, err))) return rc;
     if ((rc = dmalloc(&d_value, (size_t)Gmax, err))) return rc;
     use_tower = false;
-    if (F == TOWER_F && PP <= 256 && !getenv("FPC_NO_TOWER")) {
+    if (F == TOWER_F && PP <= 256 && 256 / PP <= 2 && !getenv("FPC_NO_TOWER")) {   // the fused value head reduces at most two games per block
       const size_t per = (size_t)9 * 128 * 128;
       if ((rc = dmalloc(&towerW, per * (2 * nblocks + 2), err)) || (rc = dmalloc(&towerB, (size_t)128 * (2 * nblocks + 2), err))) return rc;
       for (int i = 0; i < nblocks; ++i) {
@@ -1114,7 +1116,7 @@ struct NN {
     constexpr int BKS = CINC < 64 ? CINC : 64;
     constexpr int IMG = (CONV_BM + 2 * CONV_HMAX) * CINC * 2;
     constexpr int lds = (IMG > CONV_BM * 64 * 4 ? IMG : CONV_BM * 64 * 4) + 3 * CONV_BN * BKS * 2 + CONV_BM;
-    static bool attr = false;
+    bool &attr = attr_conv[DT][CINC == 32 ? 0 : CINC == 64 ? 1 : 2];    // per engine, hence per device
     if (!attr) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3x3<DT, CINC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr = true;
@@ -1156,7 +1158,7 @@ struct NN {
       t.in16 = in16 + (size_t)guard * 32; t.Wstem = stem.w; t.bstem = stem.b; t.Wt = towerW; t.bt = towerB;
       t.out = act[0] + (size_t)guard * F; t.L = 2 * nblocks; t.P = P; t.R = dc.R; t.PP = PP; t.gpb = 256 / PP; t.n_games = n;
       t.heads = 1; t.xfc = xfc; t.vw = vw; t.value = value_out; t.vb = vb; t.Kp = Kp; t.A_ch = dc.A_ch;
-      static bool attr = false;
+      bool &attr = attr_tower[DT];
       if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, TOWER_LDS); attr = true; }
       hipLaunchKernelGGL((k_tower<DT>), dim3((n + t.gpb - 1) / t.gpb), dim3(TOWER_THREADS), TOWER_LDS, stream, t);
       const hipError_t le = hipGetLastError();
@@ -1213,7 +1215,7 @@ struct NN {
     if (rc) return rc;
     if ((rc = dtype ? forward_t<1>(n, nullptr, d_value, err) : forward_t<0>(n, nullptr, d_value, err))) return rc;
     const size_t lds = (size_t)Kp * 2;
-    static bool attr = false;
+    bool &attr = attr_gemv;
     if (!attr) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_gemv<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_policy_gemv<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);

@@ -859,14 +859,17 @@ __global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double C
       const int to = flat_to(c, t.mv[nb + n], &from);
       int e = make_move_lane0(&s.b, from, to) ? 0 : ERR_MOVE;
       int ns = t.nboards[g];
-      if (ns >= t.board_cap) { e |= ERR_CAP_BOARDS; ns = t.board_cap - 1; } else t.nboards[g] = ns + 1;
-      t.bslot[nb + n] = ns;
+      if (ns >= t.board_cap) { e |= ERR_CAP_BOARDS; ns = -1; } else { t.nboards[g] = ns + 1; t.bslot[nb + n] = ns; }
       s.first_legal = ns;                    // broadcast through LDS
       if (e) t.err[g] |= e;
     }
     __syncthreads();
     slot = s.first_legal;
     __syncthreads();
+    if (slot < 0) {                          // board pool exhausted: the game leaves the search, nothing is overwritten
+      if (lane == 0) { t.alive[g] = 0; t.leaf_node[g] = -1; t.leaf_slot[g] = -1; }
+      return;
+    }
   } else {
     lds_load_board(&s, &pool[slot]);
   }

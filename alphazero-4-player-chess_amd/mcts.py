@@ -50,12 +50,7 @@ class MCTS:
         import weights
         ver = _param_version(self.neural_net)
         if getattr(eng, "weights_version", None) != ver:
-            was_training = self.neural_net.training
-            dev = next(self.neural_net.parameters()).device
-            blob = weights.export_weights(self.neural_net, self.nn_dtype)
-            self.neural_net.to(dev)
-            self.neural_net.train(was_training)
-            eng.load_weights(blob)
+            eng.load_weights(weights.export_weights(self.neural_net, self.nn_dtype))   # the module stays where it is
             eng.weights_version = _param_version(self.neural_net)
 
     def add_dirichlet_noise(self, policy, device):

@@ -12,11 +12,16 @@ import numpy as np
 import torch
 
 
+def _cpu(t):
+    """a detached fp32 host copy; the caller's module stays on its device"""
+    return t.detach().to("cpu", torch.float32)
+
+
 def _fold(conv, bn):
-    w = conv.weight.detach().float()
-    b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0])
-    s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
-    return w * s.view(-1, 1, 1, 1), (b - bn.running_mean.detach().float()) * s + bn.bias.detach().float()
+    w = _cpu(conv.weight)
+    b = _cpu(conv.bias) if conv.bias is not None else torch.zeros(w.shape[0])
+    s = _cpu(bn.weight) / torch.sqrt(_cpu(bn.running_var) + bn.eps)
+    return w * s.view(-1, 1, 1, 1), (b - _cpu(bn.running_mean)) * s + _cpu(bn.bias)
 
 
 def _to16(t, dtype):
@@ -37,7 +42,6 @@ def _conv_section(w, b, cin_pad, cout_pad, dtype):
 
 def export_weights(model, dtype=0):
     """model: ResNet in eval semantics.  dtype 0 = bf16, 1 = fp16.  Returns bytes."""
-    model = model.cpu()
     F = model.startBlock[0].weight.shape[0]
     nblocks = len(model.backBone)
     A_ch = model.policyHead[0].weight.shape[0]
@@ -62,7 +66,7 @@ def export_weights(model, dtype=0):
     w, b = _fold(model.valueHead[0], model.valueHead[1])
     secs += _conv_section(w, b, F, 128, dtype)
     # policy Linear: in index ch*RR+pos -> pos*A_ch+ch ; pad to [Np][Kp]
-    fw = fc.weight.detach().float().view(A, A_ch, RR).permute(0, 2, 1).reshape(A, A)
+    fw = _cpu(fc.weight).view(A, A_ch, RR).permute(0, 2, 1).reshape(A, A)
     t16 = torch.bfloat16 if dtype == 0 else torch.float16
     fwp = torch.zeros(Np, Kp, dtype=t16)
     fwp[:A, :A] = fw.to(t16)
@@ -74,13 +78,13 @@ def export_weights(model, dtype=0):
     secs.append(wf.view(torch.int16).numpy().tobytes())
     del wf
     fb = np.zeros(Np, np.float32)
-    fb[:A] = fc.bias.detach().float().numpy()
+    fb[:A] = _cpu(fc.bias).numpy()
     secs.append(fb.tobytes())
     vfc = model.valueHead[4]
     vw = torch.zeros(RR, 32)
-    vw[:, :24] = vfc.weight.detach().float().view(24, RR).t()
+    vw[:, :24] = _cpu(vfc.weight).view(24, RR).t()
     secs.append(vw.numpy().astype(np.float32).tobytes())
-    secs.append(struct.pack("<f", float(vfc.bias.detach().float().item())))
+    secs.append(struct.pack("<f", float(_cpu(vfc.bias).item())))
     out = bytearray(struct.pack("<4s8i28x", b"FPCW", 2, R, F, nblocks, dtype, A_ch, Np, Kp))
     assert len(out) == 64
     for s in secs:

@@ -1,0 +1,62 @@
+"""The HIP network and search on a real MI355X against fixtures recorded from the reference's OWN
+net.py (oracle/gen_net_golden.py): north_star's float bar -- policy/value logits within 1e-3 of
+the reference's fp32 PyTorch-CPU path -- on the configurations the benchmark runs, plus the
+recorded-network and 800-simulation searches and the training batch."""
+import numpy as np
+import pytest
+
+import net_cases as nc
+from fpc_testlib import make_engine
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3          # BASELINE.json north_star: "policy/value logits within 1e-3"
+
+
+def _forward_vs_fixture(R, blocks, hidden, dtype):
+    import torch
+    import weights
+    fx = nc.load_net_fixture(R, blocks, hidden)
+    model = nc.fixture_model(fx)                       # checksum-proven equal to the reference's net.py module
+    boards = nc.fixture_boards(fx)
+    n = len(boards)
+    eng = make_engine("gpu", R, nc.INV_OF[R], max_games=n, max_sims=4, nn_dtype=dtype)
+    eng.load_weights(weights.export_weights(model, dtype))
+    del model
+    enc = np.concatenate([eng.encode([b]) for b in boards])          # per-position rotation, as the fixture
+    x = torch.from_numpy(enc).cuda()
+    lg = torch.empty(n, eng.A, device="cuda")
+    va = torch.empty(n, device="cuda")
+    torch.cuda.synchronize()
+    eng.nn_forward(x.data_ptr(), n, lg.data_ptr(), va.data_ptr())
+    lg = lg.cpu().numpy()
+    el = float(np.abs(lg[:, fx["idx"]] - fx["logits"]).max())
+    ev = float(np.abs(va.cpu().numpy() - fx["value"]).max())
+    es = float(np.abs(lg.astype(np.float64).sum(axis=1) - fx["rowsum"]).max() / lg.shape[1])     # mean error over ALL A logits
+    print("reference-net fixture R=%d ResNet(%d,%d) %s: max|dlogit|=%.3e max|dvalue|=%.3e mean-row-err=%.2e (|logit|max %.3f)" % (
+        R, blocks, hidden, "fp16" if dtype else "bf16", el, ev, es, float(fx["absmax"].max())))
+    eng.close()
+    return el, ev
+
+
+@pytest.mark.parametrize("R,blocks,hidden,dtype", [(14, 10, 128, 0), (14, 10, 128, 1), (14, 20, 256, 1), (14, 20, 256, 0),
+                                                   (8, 10, 128, 0), (8, 10, 128, 1), (8, 4, 64, 1), (8, 4, 64, 0)])
+def test_logits_vs_reference_net_fixture(R, blocks, hidden, dtype):
+    """configs[1] = ResNet(10,128) bf16 at 14x14, configs[3] = ResNet(20,256) fp16, configs[0]'s
+    ResNet(4,64); both MFMA operand types; the bound is north_star's 1e-3, not widened."""
+    el, ev = _forward_vs_fixture(R, blocks, hidden, dtype)
+    assert el < TOL and ev < TOL, (el, ev)
+
+
+@pytest.mark.parametrize("R", [8, 14])
+def test_recorded_net_search(R):
+    assert nc.case_recorded_net_search("gpu", R) >= 10
+
+
+@pytest.mark.parametrize("R", [8, 14])
+def test_search_800(R):
+    assert nc.case_search_800("gpu", R) == 2
+
+
+def test_train_batch_and_loss():
+    assert nc.case_train_batch("gpu") == 16

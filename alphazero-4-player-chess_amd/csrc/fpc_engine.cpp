@@ -638,10 +638,3 @@ int fpc_set_timing(fpc_engine *e, int enabled) {
 void *fpc_stream(fpc_engine *e) { return e ? (void *)e->stream : nullptr; }
 
 }  // extern "C"
-
-#ifdef FPC_EXP_STAMP
-// diagnostic build only (tools/stamps.py)
-extern "C" int fpc_debug_stamps(unsigned long long *out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fpc::g_stamp_dbg), sizeof(unsigned long long) * 8 * 64);
-}
-#endif

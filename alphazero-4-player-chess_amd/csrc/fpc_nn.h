@@ -10,7 +10,7 @@
 // (16x16 = 256 rows per game at 14x14), so a 3x3 convolution is an implicit GEMM whose nine taps
 // are nine row-shifted views of ONE matrix:  Y[m, co] = sum_t sum_ci X[m + off_t, ci] * W[t, co, ci]
 // -- no im2col, no bounds checks in the inner loop.  M = games*256 rows, N = Cout, K = 9*Cin.
-// Kernels: k_tower (whole residual tower + head convs, activations LDS-resident, hidden = 128),
+// Kernels: k_tower (fpc_tower.h: whole residual tower + head convs, activations LDS-resident, hidden = 128),
 // k_conv3x3 (one conv per launch, any hidden width), k_fc256 (weight-streaming policy Linear).
 // All use v_mfma_f32_32x32x16_{bf16,f16} and a 16-byte-chunk XOR swizzle in LDS that makes every
 // ds_read_b128 fragment read conflict-free.
@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "fpc_tree_kernels.h"
+#include "fpc_tower.h"
 
 namespace fpc {
 
@@ -243,397 +244,6 @@ __global__ void __launch_bounds__(CONV_THREADS) k_conv3x3(ConvArgs g) {
       }
     }
     __syncthreads();
-  }
-}
-
-// ================================================================================================
-// k_tower: the whole residual tower (stem + 2*Nb convolutions, F = 128) in ONE launch with the
-// activations of a game never leaving the CU.  One block (8 waves, 2 per SIMD) owns the bordered
-// grids of gpb = 256/PP whole games (one game at 14x14).  LDS (160 KiB exactly):
-//   img  64 kB   the current layer's INPUT image, 256 rows x 128 ch, XOR-swizzled 16-B chunks
-//   ring 96 kB   3 slots x [128 cout][128 cin] = one whole tap of weights per stage (9 stages/layer)
-// The residual x_l lives packed in registers in accumulator layout, so after the last tap of a layer
-// (barrier) the image is dead and the layer's output is written IN PLACE from the accumulators:
-//   conv1: img(x) -> acc -> ReLU -> img(t)        conv2: img(t) -> acc + res -> ReLU -> img(x'), res
-// Both heads' convolutions run as two more layers of the same stream: the value conv (only its 32
-// live output columns are computed) feeds Flatten+Linear+Tanh directly from the accumulators, the
-// policy conv writes ReLU'd 16-bit rows in place and the image is then copied, position-major, into
-// the policy Linear's input matrix.  Weights are L2-resident and register-prefetched two stages ahead straight across layer boundaries.
-// Tap addressing wraps modulo 256 rows: a wrapped row only ever feeds a border output, and border /
-// unused rows are never written, so they stay zero (= the conv's zero padding) for every layer.
-// ================================================================================================
-struct TowerArgs {
-  const uint16_t *in16;   // encoded input grid [rows][32], base past the guard rows
-  const uint16_t *Wstem;  // [9][128][32]
-  const float *bstem;     // [128]
-  const uint16_t *Wt;     // [L][9][128][128]
-  const float *bt;        // [L][128]
-  uint16_t *out;          // final activations, grid layout [rows][128], base past the guard rows (heads == 0)
-  // fused heads (heads == 1): layer L = value conv (24 of 128 cout used), layer L+1 = policy conv
-  uint16_t *xfc;          // compact policy-Linear input [game][Kp]: index q*A_ch + ch
-  const float *vw;        // value Linear weights [R*R][32]
-  float *value;           // [n_games] = tanh(vb + sum relu(vconv) * vw)
-  float vb;
-  int L, P, R, PP, gpb, n_games, heads, Kp, A_ch;
-  // fused state encoding (boards != null; replaces in16): the block encodes its games' leaf positions
-  // itself -- GetEncodedStates (board.cpp:305-356) exactly as k_encode writes it, batch-wide rotation
-  // by the first live leaf's turn included (Q6) -- so the search needs no separate encode launch
-  const fpc_board *boards;
-  const int *leaf_slot, *leaf_turn;
-  int board_stride;
-  uint16_t one16;
-};
-
-// Diagnostic build only (-DFPC_EXP_STAMP, tools/stamps.py): s_memtime stamps that tell where a wave's
-// cycles go.  No stamp executes in the product build.
-#ifdef FPC_EXP_STAMP
-__device__ unsigned long long g_stamp_dbg[8 * 64];
-#define FPC_STAMP(V_) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V_) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#define FPC_STAMP_ACC(SUM_, A_, B_) SUM_ += (B_) - (A_);
-#else
-#define FPC_STAMP(V_) {}
-#define FPC_STAMP_ACC(SUM_, A_, B_) {}
-#endif
-
-constexpr int TOWER_F = 128, TOWER_THREADS = 512;
-constexpr int TOWER_IMG = 256 * TOWER_F * 2;            // 65536
-constexpr int TOWER_STAGE = 128 * 128 * 2;              // 32768: one tap
-constexpr int TOWER_LDS = TOWER_IMG + 3 * TOWER_STAGE;  // 163840 = 160 KiB
-
-template <int DT>
-__global__ void __launch_bounds__(TOWER_THREADS) k_tower(TowerArgs g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char *img = smem, *ring = smem + TOWER_IMG;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int rows_used = g.gpb * g.PP;
-  const long m0 = (long)blockIdx.x * rows_used;
-  const int game0 = blockIdx.x * g.gpb;
-
-  // The accumulators hold the TRANSPOSED tile (MFMA called as W x X^T): lane l owns grid position
-  // (l & 31) of each of its two 32-row tiles and, per accumulator register r, output channel
-  // (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the 32-channel tile -- four consecutive channels per register
-  // quad, so an epilogue packs them into one 8-byte LDS write and needs one row predicate per tile.
-  bool rowin[2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int row = wm * 64 + a * 32 + (lane & 31);
-    const int gi = row / g.PP, pos = row % g.PP, pi = pos / g.P, pj = pos % g.P;
-    rowin[a] = row < rows_used && game0 + gi < g.n_games && pi >= 1 && pi <= g.R && pj >= 1 && pj <= g.R;
-  }
-
-  // zero the image (borders / unused rows must read as zero for every layer)
-  for (int c = tid; c < TOWER_IMG / 16; c += TOWER_THREADS) reinterpret_cast<u32x4_t *>(img)[c] = u32x4_t{0u, 0u, 0u, 0u};
-  // encoded input (32 channels, 64-byte rows) -> ring slot 2, which the stem does not use for weights
-  unsigned char *enc = ring + 2 * TOWER_STAGE;
-  // fused encode: the block's leaf boards (288 B each) are staged in ring slot 1 (idle until the
-  // stem's second stage) with the slot lookup and the batch rotation's lookups in flight together
-  int rot_k = 0;
-  fpc_board *lb = reinterpret_cast<fpc_board *>(ring + TOWER_STAGE);
-  int *lslot = reinterpret_cast<int *>(ring + TOWER_STAGE + 4 * sizeof(fpc_board));
-  if (g.boards) {
-    constexpr int WPB = (int)(sizeof(fpc_board) / 4);            // 72 words per board
-    const int bg = tid / WPB, bw = tid % WPB;
-    const bool mine = bg < g.gpb && game0 + bg < g.n_games;
-    const int slot = mine ? g.leaf_slot[game0 + bg] : -1;
-    rot_k = first_leaf_turn(g.leaf_slot, g.leaf_turn, g.n_games);
-    if (mine) {
-      if (slot >= 0) reinterpret_cast<uint32_t *>(lb + bg)[bw] =
-          reinterpret_cast<const uint32_t *>(g.boards + (size_t)(game0 + bg) * g.board_stride + slot)[bw];
-      if (bw == 0) lslot[bg] = slot;
-    }
-    __syncthreads();
-  }
-  for (int c = tid; c < 256 * 4; c += TOWER_THREADS) {
-    const int row = c >> 2, j = c & 3;
-    u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
-    if (!g.boards) {
-      if (row < rows_used) v = *reinterpret_cast<const u32x4_t *>(g.in16 + (m0 + row) * 32 + j * 8);
-    } else {
-      const int gi = row / g.PP, pos = row % g.PP, pi = pos / g.P, pj = pos % g.P;
-      if (row < rows_used && game0 + gi < g.n_games && pi >= 1 && pi <= g.R && pj >= 1 && pj <= g.R && lslot[gi] >= 0) {
-        const fpc_board *b = lb + gi;            // (a dead game's input stays all zero)
-        const uint8_t p = b->sq[rot90_src(g.R, rot_k, pi - 1, pj - 1)];
-        if (present(p)) {
-          int plane = 6 * ((colour_of(p) - b->turn) & 3) + type_of(p) - 1;   // Q7: -1 wraps to 23
-          if (plane < 0) plane += 24;
-          if ((plane >> 3) == j) v[(plane & 7) >> 1] = (plane & 1) ? (uint32_t)g.one16 << 16 : (uint32_t)g.one16;
-        }
-      }
-    }
-    *reinterpret_cast<u32x4_t *>(enc + lds_off<32>(row, j)) = v;
-  }
-
-  f32x16_t acc00, acc01, acc10, acc11;
-#define FPC_ZERO_ACC() \
-  _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
-  FPC_ZERO_ACC();
-  uint32_t res[2][2][8];          // residual x_l, packed 16-bit channel pairs in accumulator layout
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int k = 0; k < 8; ++k) res[a][b][k] = 0u;
-
-  // epilogue of one layer, from registers, IN PLACE into the image: v = acc + bias (+res); ReLU;
-  // 16-bit at interior rows; KEEP_RES also refreshes the residual registers.  BIAS_ points at the
-  // layer's 128 biases in LDS (published through a free weight-ring slot before the layer barrier).
-#define FPC_TOWER_EPI(ADD_RES, KEEP_RES, BIAS_)                                                      \
-  {                                                                                                  \
-    _Pragma("unroll") for (int b = 0; b < 2; ++b) _Pragma("unroll") for (int q = 0; q < 4; ++q) {    \
-      const int c0_ = wn * 64 + b * 32 + 8 * q + 4 * (lane >> 5);                                    \
-      const f32x4_t bs_ = *reinterpret_cast<const f32x4_t *>((BIAS_) + c0_);                         \
-      _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                \
-        const f32x16_t accv = a == 0 ? (b == 0 ? acc00 : acc01) : (b == 0 ? acc10 : acc11);          \
-        float v0 = accv[4 * q] + bs_[0], v1 = accv[4 * q + 1] + bs_[1];                              \
-        float v2 = accv[4 * q + 2] + bs_[2], v3 = accv[4 * q + 3] + bs_[3];                          \
-        if (ADD_RES) {                                                                               \
-          const uint32_t p0 = res[a][b][2 * q], p1 = res[a][b][2 * q + 1];                           \
-          v0 += E16<DT>::to_f32((uint16_t)(p0 & 0xffffu)); v1 += E16<DT>::to_f32((uint16_t)(p0 >> 16)); \
-          v2 += E16<DT>::to_f32((uint16_t)(p1 & 0xffffu)); v3 += E16<DT>::to_f32((uint16_t)(p1 >> 16)); \
-        }                                                                                            \
-        v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;                                          \
-        v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;                                          \
-        const uint32_t h01 = E16<DT>::pack2(v0, v1), h23 = E16<DT>::pack2(v2, v3);                   \
-        if (KEEP_RES) { res[a][b][2 * q] = h01; res[a][b][2 * q + 1] = h23; }                        \
-        if (rowin[a]) {                                                                              \
-          const int row = wm * 64 + a * 32 + (lane & 31);                                            \
-          *reinterpret_cast<u32x2_t *>(img + lds_off<TOWER_F>(row, c0_ >> 3) + (c0_ & 7) * 2) = u32x2_t{h01, h23}; \
-        }                                                                                            \
-      }                                                                                              \
-    }                                                                                                \
-  }
-
-  // value head from the accumulators (net.py:28-35): relu(conv + bias)[q][ch] . vw[q][ch], ch < 24
-#define FPC_VALUE_EPI(BIAS_)                                                                         \
-  if (wn == 0) {                                                                                     \
-    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                  \
-      if (rowin[a]) {                                                                                \
-        const f32x16_t accv = a == 0 ? acc00 : acc10;                                                \
-        const int row = wm * 64 + a * 32 + (lane & 31);                                              \
-        const int gi = row / g.PP, pos = row % g.PP;                                                 \
-        const int qp = (pos / g.P - 1) * g.R + (pos % g.P - 1);                                      \
-        float pv = 0.f;                                                                              \
-        _Pragma("unroll") for (int q = 0; q < 3; ++q) {          /* channels 8q + 4(l>>5) + i < 24 */ \
-          const int c0_ = 8 * q + 4 * (lane >> 5);                                                   \
-          const f32x4_t bs_ = *reinterpret_cast<const f32x4_t *>((BIAS_) + c0_);                     \
-          const f32x4_t w4_ = *reinterpret_cast<const f32x4_t *>(g.vw + qp * 32 + c0_);              \
-          _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-            float v = accv[4 * q + i] + bs_[i];                                                      \
-            v = v > 0.f ? v : 0.f;                                                                   \
-            v = E16<DT>::to_f32(E16<DT>::from_f32(v));   /* same rounding point as the unfused path */ \
-            pv += v * w4_[i];                                                                        \
-          }                                                                                          \
-        }                                                                                            \
-        if (gi == 0) vsum0 += pv; else vsum1 += pv;                                                  \
-      }                                                                                              \
-    }                                                                                                \
-  }
-
-  // ---------------- stem: enc(32 ch) -> img, 9 stages of [128][32] through ring slots 0/1 ----------
-  {
-    u32x4_t w0, w1;
-#define FPC_SLOAD(REG, S_) REG = *reinterpret_cast<const u32x4_t *>(g.Wstem + ((long)(S_) * 128 + (tid >> 2)) * 32 + (tid & 3) * 8);
-#define FPC_SSTORE(REG, SLOT_) *reinterpret_cast<u32x4_t *>(ring + (SLOT_) * TOWER_STAGE + lds_off<32>(tid >> 2, tid & 3)) = REG;
-    FPC_SLOAD(w0, 0);
-    FPC_SLOAD(w1, 1);
-    const float bstem_ = g.bstem[tid & 127];
-    FPC_SSTORE(w0, 0);
-    __syncthreads();
-#define FPC_SSTEP(S_, REG_NEXT, REG_FREE)                                                            \
-    {                                                                                                \
-      const int s_ = (S_);                                                                           \
-      if (s_ + 2 < 9) FPC_SLOAD(REG_FREE, s_ + 2);                                                   \
-      const int arow_ = (s_ / 3 - 1) * g.P + (s_ % 3 - 1) + wm * 64 + (lane & 31);                   \
-      const unsigned char *wb_ = ring + (s_ & 1) * TOWER_STAGE;                                      \
-      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                             \
-        const int j_ = ks * 2 + (lane >> 5);                                                         \
-        const u32x4_t fa0 = *reinterpret_cast<const u32x4_t *>(enc + lds_off<32>(arow_ & 255, j_));           \
-        const u32x4_t fa1 = *reinterpret_cast<const u32x4_t *>(enc + lds_off<32>((arow_ + 32) & 255, j_));    \
-        const u32x4_t fb0 = *reinterpret_cast<const u32x4_t *>(wb_ + lds_off<32>(wn * 64 + (lane & 31), j_));      \
-        const u32x4_t fb1 = *reinterpret_cast<const u32x4_t *>(wb_ + lds_off<32>(wn * 64 + 32 + (lane & 31), j_)); \
-        acc00 = E16<DT>::mfma(fb0, fa0, acc00); acc01 = E16<DT>::mfma(fb1, fa0, acc01);              \
-        acc10 = E16<DT>::mfma(fb0, fa1, acc10); acc11 = E16<DT>::mfma(fb1, fa1, acc11);              \
-      }                                                                                              \
-      if (s_ + 1 < 9) FPC_SSTORE(REG_NEXT, (s_ + 1) & 1);                                            \
-      if (s_ == 8 && tid < 128) reinterpret_cast<float *>(ring + TOWER_STAGE)[tid] = bstem_;   /* slot 1 is free after stage 7 */ \
-      __syncthreads();                                                                               \
-    }
-    FPC_SSTEP(0, w1, w0); FPC_SSTEP(1, w0, w1); FPC_SSTEP(2, w1, w0); FPC_SSTEP(3, w0, w1); FPC_SSTEP(4, w1, w0);
-    FPC_SSTEP(5, w0, w1); FPC_SSTEP(6, w1, w0); FPC_SSTEP(7, w0, w1); FPC_SSTEP(8, w1, w0);
-#undef FPC_SSTEP
-#undef FPC_SLOAD
-#undef FPC_SSTORE
-    FPC_TOWER_EPI(false, true, reinterpret_cast<const float *>(ring + TOWER_STAGE));
-    FPC_ZERO_ACC();
-    __syncthreads();                  /* slot 1 (the stem's biases) is rewritten by the tower's second tap */
-  }
-
-  // ---------------- tower: L layers x 9 stages (one tap = [128 cout][128 cin] per stage) ----------
-  const int total = (g.L + (g.heads ? 2 : 0)) * 9;
-  float vsum0 = 0.f, vsum1 = 0.f;     // value-head partial dot products of this lane (game 0 / 1 of the block)
-  u32x4_t rb0[4], rb1[4];
-#define FPC_TLOAD(REGS, G_)                                                                          \
-  {                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
-      const int c_ = tid + TOWER_THREADS * i;                                                        \
-      REGS[i] = *reinterpret_cast<const u32x4_t *>(g.Wt + (long)(G_) * (128 * 128) + (long)c_ * 8);  \
-    }                                                                                                \
-  }
-#define FPC_TSTORE(REGS, SLOT_)                                                                      \
-  {                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
-      const int c_ = tid + TOWER_THREADS * i, row_ = c_ >> 4, j_ = c_ & 15;                          \
-      *reinterpret_cast<u32x4_t *>(ring + (SLOT_) * TOWER_STAGE + lds_off<TOWER_F>(row_, j_)) = REGS[i]; \
-    }                                                                                                \
-  }
-#define FPC_TSTORE2(REGS, SLOT_, H_)                                                                 \
-  {                                                                                                  \
-    _Pragma("unroll") for (int i = 2 * (H_); i < 2 * (H_) + 2; ++i) {                                \
-      const int c_ = tid + TOWER_THREADS * i, row_ = c_ >> 4, j_ = c_ & 15;                          \
-      *reinterpret_cast<u32x4_t *>(ring + (SLOT_) * TOWER_STAGE + lds_off<TOWER_F>(row_, j_)) = REGS[i]; \
-    }                                                                                                \
-  }
-  float bcur = 0.f;                   // this thread's share of the current layer's 128 biases
-  if (total > 0) {
-    FPC_TLOAD(rb0, 0);
-    if (total > 1) FPC_TLOAD(rb1, 1);
-    FPC_TSTORE(rb0, 0);
-  }
-  __syncthreads();
-#define FPC_FRAG(KS_, A0, A1, B0, B1)                                                                \
-  A0 = *reinterpret_cast<const u32x4_t *>(img + lds_off<TOWER_F>(ra0_, (KS_) * 2 + jh_));            \
-  A1 = *reinterpret_cast<const u32x4_t *>(img + lds_off<TOWER_F>(ra1_, (KS_) * 2 + jh_));            \
-  B0 = *reinterpret_cast<const u32x4_t *>(wb_ + lds_off<TOWER_F>(rb0_, (KS_) * 2 + jh_));            \
-  B1 = *reinterpret_cast<const u32x4_t *>(wb_ + lds_off<TOWER_F>(rb1_, (KS_) * 2 + jh_));
-#define FPC_MMA(A0, A1, B0, B1)                                                                      \
-  if (mode_ != 1) {       /* W x X^T: the accumulators hold the transposed tile */                   \
-    acc00 = E16<DT>::mfma(B0, A0, acc00); acc01 = E16<DT>::mfma(B1, A0, acc01);                      \
-    acc10 = E16<DT>::mfma(B0, A1, acc10); acc11 = E16<DT>::mfma(B1, A1, acc11);                      \
-  } else if (wn == 0) {   /* value conv: only the 32 live output columns */                          \
-    acc00 = E16<DT>::mfma(B0, A0, acc00); acc10 = E16<DT>::mfma(B0, A1, acc10);                      \
-  }
-#define FPC_TSTEP(G_, REGS_NEXT, REGS_FREE, MODE_)   /* MODE_ literal: 0 tower layer, 1 value conv, 2 policy conv */ \
-  {                                                                                                  \
-    const int g_ = (G_), l_ = g_ / 9, tap_ = g_ % 9;                                                 \
-    constexpr int mode_ = (MODE_);                                                                   \
-    FPC_STAMP(ts0);                                                                                  \
-    if (tap_ == 0) bcur = g.bt[l_ * 128 + (tid & 127)];                                              \
-    const int arow_ = (tap_ / 3 - 1) * g.P + (tap_ % 3 - 1) + wm * 64 + (lane & 31);                 \
-    const unsigned char *wb_ = ring + (g_ % 3) * TOWER_STAGE;                                        \
-    /* fragment reads software-pipelined one k-step ahead of the MFMAs that consume them */         \
-    const int ra0_ = arow_ & 255, ra1_ = (arow_ + 32) & 255;                                         \
-    const int rb0_ = wn * 64 + (lane & 31), rb1_ = rb0_ + 32, jh_ = lane >> 5;                       \
-    u32x4_t pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;                                                  \
-    FPC_FRAG(0, pa0, pa1, pb0, pb1);                                                                 \
-    FPC_FRAG(1, qa0, qa1, qb0, qb1);                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-    /* the stage's other memory traffic rides between the MFMA groups: the tap two stages ahead is  \
-       requested behind k-step 1, the next tap goes to its (idle) ring slot behind k-steps 4-5 */    \
-    FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(2, pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); \
-    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(3, qa0, qa1, qb0, qb1);  \
-    if (g_ + 2 < total) FPC_TLOAD(REGS_FREE, g_ + 2);                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-    FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(4, pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); \
-    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(5, qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); \
-    FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(6, pa0, pa1, pb0, pb1);  \
-    if (g_ + 1 < total) FPC_TSTORE2(REGS_NEXT, (g_ + 1) % 3, 0);                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0); FPC_FRAG(7, qa0, qa1, qb0, qb1);  \
-    if (g_ + 1 < total) FPC_TSTORE2(REGS_NEXT, (g_ + 1) % 3, 1);                                     \
-    /* THE stage barrier sits here, right behind the ring stores, not at the stage's end: it       \
-       publishes the next tap (every wave stored before it) and proves that nobody still reads the   \
-       slot the NEXT stage will overwrite (a wave passing it has finished stage g-1).  A wave then   \
-       runs from the last MFMAs of this stage straight into the next stage's fragment reads, so the  \
-       two waves of a SIMD drift out of phase and hide each other's LDS latency. */                  \
-    __syncthreads();                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-    FPC_MMA(pa0, pa1, pb0, pb1); __builtin_amdgcn_sched_barrier(0);                                  \
-    FPC_MMA(qa0, qa1, qb0, qb1); __builtin_amdgcn_sched_barrier(0);                                  \
-    FPC_STAMP(ts1);                                                                                  \
-    FPC_STAMP(ts2);                                                                                  \
-    if (tap_ == 8) {                                                                                 \
-      /* ring slot (g+2)%3 is idle until the end of the next stage: it carries the layer's biases */ \
-      const float *bl_ = reinterpret_cast<const float *>(ring + ((g_ + 2) % 3) * TOWER_STAGE);       \
-      if (tid < 128) const_cast<float *>(bl_)[tid] = bcur;                                           \
-      __syncthreads();               /* every wave is done reading this layer's input image */       \
-      FPC_STAMP(ts3);                                                                                \
-      if (mode_ == 1) { FPC_VALUE_EPI(bl_); }                                                        \
-      else if (mode_ == 2) { FPC_TOWER_EPI(false, false, bl_); }   /* policy conv: ReLU rows in place */  \
-      else if (l_ & 1) { FPC_TOWER_EPI(true, true, bl_); } else { FPC_TOWER_EPI(false, false, bl_); } \
-      FPC_ZERO_ACC();                                                                                \
-      FPC_STAMP(ts4);                                                                                \
-      FPC_STAMP_ACC(tsum[3], ts2, ts3); FPC_STAMP_ACC(tsum[4], ts3, ts4);                            \
-      ts2 = ts4;                                                                                     \
-      __syncthreads();               /* the next layer's input image is complete */                  \
-    }                                                                                                \
-    FPC_STAMP(ts5);                                                                                  \
-    FPC_STAMP_ACC(tsum[0], ts0, ts1); FPC_STAMP_ACC(tsum[1], ts1, ts2 == ts4 ? ts1 : ts2); FPC_STAMP_ACC(tsum[2], ts2, ts5); \
-  }
-  const int tower_stages = g.L * 9;            // even
-  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 1, ts5 = 0, tsum[5] = {0, 0, 0, 0, 0};
-  (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)ts4; (void)ts5; (void)tsum;
-  for (int gs = 0; gs < tower_stages; gs += 2) {
-    FPC_TSTEP(gs, rb1, rb0, 0);
-    FPC_TSTEP(gs + 1, rb0, rb1, 0);
-  }
-  if (g.heads) {
-    const int v0 = tower_stages, p0 = tower_stages + 9;
-    FPC_TSTEP(v0 + 0, rb1, rb0, 1); FPC_TSTEP(v0 + 1, rb0, rb1, 1); FPC_TSTEP(v0 + 2, rb1, rb0, 1);
-    FPC_TSTEP(v0 + 3, rb0, rb1, 1); FPC_TSTEP(v0 + 4, rb1, rb0, 1); FPC_TSTEP(v0 + 5, rb0, rb1, 1);
-    FPC_TSTEP(v0 + 6, rb1, rb0, 1); FPC_TSTEP(v0 + 7, rb0, rb1, 1); FPC_TSTEP(v0 + 8, rb1, rb0, 1);
-    FPC_TSTEP(p0 + 0, rb0, rb1, 2); FPC_TSTEP(p0 + 1, rb1, rb0, 2); FPC_TSTEP(p0 + 2, rb0, rb1, 2);
-    FPC_TSTEP(p0 + 3, rb1, rb0, 2); FPC_TSTEP(p0 + 4, rb0, rb1, 2); FPC_TSTEP(p0 + 5, rb1, rb0, 2);
-    FPC_TSTEP(p0 + 6, rb0, rb1, 2); FPC_TSTEP(p0 + 7, rb1, rb0, 2); FPC_TSTEP(p0 + 8, rb0, rb1, 2);
-  }
-#undef FPC_TSTEP
-#undef FPC_FRAG
-#undef FPC_MMA
-#undef FPC_TLOAD
-#undef FPC_TSTORE
-#undef FPC_TSTORE2
-#undef FPC_TOWER_EPI
-#undef FPC_VALUE_EPI
-#undef FPC_ZERO_ACC
-
-#ifdef FPC_EXP_STAMP
-  if (lane == 0 && blockIdx.x % 37 == 0 && blockIdx.x / 37 < 4)
-    for (int i = 0; i < 5; ++i) g_stamp_dbg[((blockIdx.x / 37) * 8 + wave) * 8 + i] = tsum[i];
-#endif
-  if (!g.heads) {
-    // final x -> global grid (whole rows: borders are zero in the image)
-    for (int c = tid; c < 256 * 16; c += TOWER_THREADS) {
-      const int row = c >> 4, j = c & 15;
-      if (row < rows_used && game0 + row / g.PP < g.n_games)
-        *reinterpret_cast<u32x4_t *>(g.out + (m0 + row) * TOWER_F + j * 8) = *reinterpret_cast<const u32x4_t *>(img + lds_off<TOWER_F>(row, j));
-    }
-    return;
-  }
-  // policy conv rows (ReLU'd, in the image) -> Linear input, position-major: A_ch*2 bytes per position
-  {
-    const int cpr = g.A_ch / 8;                       // 16-byte chunks per position (A_ch % 8 == 0)
-    for (int c = tid; c < 256 * 16; c += TOWER_THREADS) {
-      const int row = c >> 4, j = c & 15;
-      if (row >= rows_used || j >= cpr) continue;
-      const int gi = row / g.PP, pos = row % g.PP, pi = pos / g.P, pj = pos % g.P;
-      if (game0 + gi >= g.n_games || pi < 1 || pi > g.R || pj < 1 || pj > g.R) continue;
-      const int q = (pi - 1) * g.R + (pj - 1);
-      *reinterpret_cast<u32x4_t *>(g.xfc + (long)(game0 + gi) * g.Kp + (long)q * g.A_ch + j * 8) =
-          *reinterpret_cast<const u32x4_t *>(img + lds_off<TOWER_F>(row, j));
-    }
-  }
-  // value: reduce the lane partials over the block (ring slot 0 is free now), tanh, store
-  {
-    float *red = reinterpret_cast<float *>(ring);
-    for (int off = 32; off >= 1; off >>= 1) { vsum0 += __shfl_xor(vsum0, off); vsum1 += __shfl_xor(vsum1, off); }
-    if (lane == 0) { red[wave * 2] = vsum0; red[wave * 2 + 1] = vsum1; }
-    __syncthreads();
-    if (tid < g.gpb && game0 + tid < g.n_games) {
-      float sacc = g.vb;
-      for (int w = 0; w < 8; ++w) sacc += red[w * 2 + tid];
-      g.value[game0 + tid] = tanhf(sacc);
-    }
   }
 }
 
@@ -965,8 +575,9 @@ struct NN {
   float *fcb = nullptr, *vw = nullptr;
   float *fc_part = nullptr;      // [slabs][Gpad][256] partial sums of k_fc256 (sized for 2*FC_SPLITK slabs per group)
   int fc_G1 = 0, fc_s2 = FC_SPLITK;   // work decomposition chosen at load time (plan_fc)
-  uint16_t *towerW = nullptr;    // [2*nblocks][9][128][128] contiguous copy for k_tower (F == 128)
-  float *towerB = nullptr;
+  unsigned char *towerW = nullptr;   // k_tower's weight stream: [(2*nblocks + 2) * 9 taps][32 KiB] in LDS-image order (F == 128)
+  unsigned char *stemW = nullptr;    // [9 taps][8 KiB], same order
+  float *towerB = nullptr;           // [2*nblocks + 2][256] (128 used)
   bool use_tower = false;
   void (*mark_fn)(void *, int) = nullptr;   // stage-timing hook of the engine (tag 2 = policy Linear starts)
   void *mark_ctx = nullptr;
@@ -1091,20 +702,22 @@ struct NN {
     if ((rc = dmalloc(&d_logits, (size_t)Gmax * dc.A, err))) return rc;
     if ((rc = dmalloc(&d_value, (size_t)Gmax, err))) return rc;
     use_tower = false;
-    if (F == TOWER_F && PP <= 256 && 256 / PP <= 2 && !getenv("FPC_NO_TOWER")) {   // the fused value head reduces at most two games per block
-      const size_t per = (size_t)9 * 128 * 128;
-      if ((rc = dmalloc(&towerW, per * (2 * nblocks + 2), err)) || (rc = dmalloc(&towerB, (size_t)128 * (2 * nblocks + 2), err))) return rc;
-      for (int i = 0; i < nblocks; ++i) {
-        (void)hipMemcpy(towerW + per * (2 * i), c1[i].w, per * 2, hipMemcpyDeviceToDevice);
-        (void)hipMemcpy(towerW + per * (2 * i + 1), c2[i].w, per * 2, hipMemcpyDeviceToDevice);
-        (void)hipMemcpy(towerB + 128 * (2 * i), c1[i].b, 128 * 4, hipMemcpyDeviceToDevice);
-        (void)hipMemcpy(towerB + 128 * (2 * i + 1), c2[i].b, 128 * 4, hipMemcpyDeviceToDevice);
-      }
-      // heads ride the same weight stream: layer L = value conv, layer L+1 = policy conv
-      (void)hipMemcpy(towerW + per * (2 * nblocks), vconv.w, per * 2, hipMemcpyDeviceToDevice);
-      (void)hipMemcpy(towerW + per * (2 * nblocks + 1), pconv.w, per * 2, hipMemcpyDeviceToDevice);
-      (void)hipMemcpy(towerB + 128 * (2 * nblocks), vconv.b, 128 * 4, hipMemcpyDeviceToDevice);
-      (void)hipMemcpy(towerB + 128 * (2 * nblocks + 1), pconv.b, 128 * 4, hipMemcpyDeviceToDevice);
+    if (F == 128 && !getenv("FPC_NO_TOWER")) {
+      // k_tower streams every tap as one 32 KiB block already laid out as its LDS image (fpc_tower.h);
+      // layers: c1[0], c2[0], ..., then the value conv and the policy conv
+      const int layers = 2 * nblocks + 2;
+      if ((rc = dmalloc(&towerW, (size_t)layers * 9 * TW_TAP, err)) || (rc = dmalloc(&stemW, (size_t)9 * TW_STEM_TAP, err)) ||
+          (rc = dmalloc(&towerB, (size_t)layers * 256, err))) return rc;
+      auto prep = [&](const ConvW &cw, int layer) {
+        hipLaunchKernelGGL(k_tower_prep, dim3((9 * 128 * 16 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)cw.w,
+                           towerW + (size_t)layer * 9 * TW_TAP, 9, 128);
+        (void)hipMemcpyAsync(towerB + (size_t)layer * 256, cw.b, 128 * 4, hipMemcpyDeviceToDevice, stream);
+      };
+      for (int i = 0; i < nblocks; ++i) { prep(c1[i], 2 * i); prep(c2[i], 2 * i + 1); }
+      prep(vconv, 2 * nblocks);
+      prep(pconv, 2 * nblocks + 1);
+      hipLaunchKernelGGL(k_tower_prep, dim3((9 * 128 * 4 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)stem.w, stemW, 9, 32);
+      if (hipStreamSynchronize(stream) != hipSuccess) { *err = "k_tower_prep failed"; return FPC_ENODEVICE; }
       use_tower = true;
     }
     loaded = true;
@@ -1155,12 +768,21 @@ struct NN {
       TowerArgs t{};
       t.boards = in_boards; t.leaf_slot = in_leaf_slot; t.leaf_turn = in_leaf_turn; t.board_stride = in_board_stride; t.one16 = one16();
       in_boards = nullptr;
-      t.in16 = in16 + (size_t)guard * 32; t.Wstem = stem.w; t.bstem = stem.b; t.Wt = towerW; t.bt = towerB;
-      t.out = act[0] + (size_t)guard * F; t.L = 2 * nblocks; t.P = P; t.R = dc.R; t.PP = PP; t.gpb = 256 / PP; t.n_games = n;
-      t.heads = 1; t.xfc = xfc; t.vw = vw; t.value = value_out; t.vb = vb; t.Kp = Kp; t.A_ch = dc.A_ch;
+      t.in16 = in16 + (size_t)guard * 32; t.Wstem = stemW; t.bstem = stem.b; t.Wt = towerW; t.bt = towerB;
+      t.xfc = xfc; t.vw = vw; t.value = value_out; t.vb = vb;
+      t.L = 2 * nblocks; t.P = P; t.R = dc.R; t.PP = PP; t.NR = PP - P; t.T0 = (P + 1) / 16; t.n_games = n; t.Kp = Kp; t.A_ch = dc.A_ch;
+      // row tiles of 16 grid positions per wave (two waves along M): 8x8 -> 3, 9..11 -> 5, 12..14 -> 7
+      const int mt = dc.R <= 8 ? 3 : dc.R <= 11 ? 5 : 7;
       bool &attr = attr_tower[DT];
-      if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, TOWER_LDS); attr = true; }
-      hipLaunchKernelGGL((k_tower<DT>), dim3((n + t.gpb - 1) / t.gpb), dim3(TOWER_THREADS), TOWER_LDS, stream, t);
+      if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
+        attr = true;
+      }
+      if (mt == 3) hipLaunchKernelGGL((k_tower<DT, 3>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);
+      else if (mt == 5) hipLaunchKernelGGL((k_tower<DT, 5>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);
+      else hipLaunchKernelGGL((k_tower<DT, 7>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);
       const hipError_t le = hipGetLastError();
       if (le != hipSuccess) { *err = std::string("k_tower launch failed: ") + hipGetErrorString(le); return FPC_ENODEVICE; }
     } else if ((rc = conv(stem, in16, 32, nullptr, act[0], F, F, 0))) return rc;

@@ -775,14 +775,16 @@ struct NN {
       const int mt = dc.R <= 8 ? 3 : dc.R <= 11 ? 5 : 7;
       bool &attr = attr_tower[DT];
       if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 7, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 7, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
         attr = true;
       }
-      if (mt == 3) hipLaunchKernelGGL((k_tower<DT, 3>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);
-      else if (mt == 5) hipLaunchKernelGGL((k_tower<DT, 5>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);
-      else hipLaunchKernelGGL((k_tower<DT, 7>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);
+      if (mt == 3) hipLaunchKernelGGL((k_tower<DT, 3, false>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);
+      else if (mt == 5) hipLaunchKernelGGL((k_tower<DT, 5, false>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);
+      else if (P != 16) hipLaunchKernelGGL((k_tower<DT, 7, false>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);
+      else hipLaunchKernelGGL((k_tower<DT, 7, true>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);   // 14x14: grid pitch == tile height
       const hipError_t le = hipGetLastError();
       if (le != hipSuccess) { *err = std::string("k_tower launch failed: ") + hipGetErrorString(le); return FPC_ENODEVICE; }
     } else if ((rc = conv(stem, in16, 32, nullptr, act[0], F, F, 0))) return rc;

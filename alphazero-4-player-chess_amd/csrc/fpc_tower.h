@@ -18,6 +18,11 @@
 //     tap-time ahead; one barrier per tap publishes it.
 //   * the conv zero padding is the image's zero border; the bottom border row is aliased onto the top
 //     one (row index mod NR), which makes room for the ring in the 160 KiB of LDS.
+//   * one wave per SIMD means every non-MFMA instruction competes with the MFMAs for the SIMD's issue
+//     slots (an MFMA 16x16x32 holds the issue port 8 of its 16 cycles), so the instruction stream is
+//     kept lean: fragment addresses are one VGPR + immediates (14x14: every row tile but the last is a
+//     constant 4 KiB apart), the bias enters as the accumulators' initial value, ReLU runs on packed
+//     16-bit pairs, the DMA uses the SGPR-base form.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -30,8 +35,10 @@ namespace fpc {
 typedef __attribute__((ext_vector_type(8))) __bf16 t_bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 t_f16x8;
 typedef __attribute__((ext_vector_type(4))) float t_f32x4;
+typedef __attribute__((ext_vector_type(2))) float t_f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t t_u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t t_u32x2;
+typedef __attribute__((ext_vector_type(2))) short t_i16x2;
 
 template <int DT>
 struct M16;
@@ -40,9 +47,9 @@ struct M16<0> {  // bf16
   static __device__ __forceinline__ t_f32x4 mfma(t_u32x4 a, t_u32x4 b, t_f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(t_bf16x8, a), __builtin_bit_cast(t_bf16x8, b), c, 0, 0, 0);
   }
-  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    const __bf16 a = (__bf16)lo, b = (__bf16)hi;
-    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {      // v_cvt_pk_bf16_f32, round to nearest even
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((t_f32x2{lo, hi}), b2));
   }
   static __device__ __forceinline__ float lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
   static __device__ __forceinline__ float hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
@@ -52,27 +59,39 @@ struct M16<1> {  // fp16
   static __device__ __forceinline__ t_f32x4 mfma(t_u32x4 a, t_u32x4 b, t_f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(t_f16x8, a), __builtin_bit_cast(t_f16x8, b), c, 0, 0, 0);
   }
-  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    const _Float16 a = (_Float16)lo, b = (_Float16)hi;
-    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {      // v_cvt_pk_f16_f32, round to nearest even
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((t_f32x2{lo, hi}), h2));
   }
   static __device__ __forceinline__ float lo(uint32_t p) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(p & 0xffffu)); }
   static __device__ __forceinline__ float hi(uint32_t p) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(p >> 16)); }
 };
+// ReLU of a packed pair of bf16 or fp16 values: as signed 16-bit integers every negative float (and -0)
+// is negative and every positive float keeps its order, so max(x, 0) per half is the ReLU (v_pk_max_i16)
+__device__ __forceinline__ uint32_t tw_relu2(uint32_t p) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(t_i16x2, p), (t_i16x2{0, 0})));
+}
 
 // byte offset of 16-byte chunk c of row `row` in an image whose rows have CH chunks
 __host__ __device__ constexpr int tw_lay(int CH, int row, int c) {
   return (row >> 3) * (CH * 128) + (c >> 1) * 256 + (c & 1) * 128 + (row & 7) * 16;
 }
 
+// LDS map (160 KiB exactly).  The 4 KiB in front of the image also absorb the one fragment row that a
+// border position of the first row tile reads at index -1 (its output is never stored).
 constexpr int TW_THREADS = 256;
+constexpr int TW_BIAS = 0;                       // [2][256] f32, filled by LDS-DMA (128 used per layer)
+constexpr int TW_DUMMY = 2048;                   // 512 B: where non-interior lanes send their epilogue writes
+constexpr int TW_VRED = 2560;                    // [4] f32 value-head partials
+constexpr int TW_BOARD = 2624;                   // the game's leaf board (288 B)
+constexpr int TW_IMG0 = 4096;
 constexpr int TW_IMG = 61440;                    // 240 rows x 256 B (14x14: 15 of the 16 grid rows)
 constexpr int TW_TAP = 32768;                    // [128 cout][128 cin] x 2 B
-constexpr int TW_RING = TW_IMG;                  // 3 slots
-constexpr int TW_SPARE = TW_IMG + 3 * TW_TAP;    // 159744: biases 2 x 1 KiB, value partials, leaf board
-constexpr int TW_LDS = 163840;
+constexpr int TW_RING = TW_IMG0 + TW_IMG;        // 3 slots
+constexpr int TW_LDS = TW_RING + 3 * TW_TAP;     // 163840
 constexpr int TW_STEM_TAP = 8192;                // [128 cout][32 cin] x 2 B
 constexpr int TW_ENC = TW_RING + 9 * TW_STEM_TAP;   // the stem's input image (<= 15 KiB) behind its 72 KiB of weights
+static_assert(TW_LDS == 163840, "k_tower uses the whole LDS of a CU");
 
 struct TowerArgs {
   // input: either the search's leaf boards (fused GetEncodedStates, board.cpp:305-356) or an encoded grid
@@ -92,30 +111,43 @@ struct TowerArgs {
   int L, P, R, PP, NR, T0, n_games, Kp, A_ch;
 };
 
-// One LDS-DMA piece: 64 lanes x 16 B (or x 4 B) global -> LDS with no VGPR destination.  Issued from
-// inline asm on purpose: hipcc would otherwise order every later LDS access behind a vmcnt(0) for the
-// pending LDS write.  All waits for these pieces are the explicit `s_waitcnt vmcnt(0)` statements in
-// k_tower (each followed by the barrier that publishes the data to the other waves).  M0 carries the
-// wave-uniform LDS byte address and is restored inside the same statement.
-__device__ __forceinline__ void tw_dma16(const unsigned char *gsrc_lane, uint32_t lds_addr_uniform) {
+// LDS-DMA: `PIECES` consecutive 1-KiB pieces (64 lanes x 16 B each) global -> LDS with no VGPR
+// destination, source = SGPR base + per-lane byte offset.  Issued from inline asm on purpose: hipcc
+// would otherwise order every later LDS access behind a vmcnt(0) for the pending LDS write.  All waits
+// for these pieces are the explicit `s_waitcnt vmcnt(0)` statements in k_tower (each followed by the
+// barrier that publishes the data to the other waves).  M0 carries the wave-uniform LDS byte address
+// and is restored inside the same statement.
+__device__ __forceinline__ void tw_dma_8k(const unsigned char *gsrc_uniform, uint32_t lane_off, uint32_t lds_addr_uniform) {
   uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr_uniform) : "memory");
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\ts_add_u32 m0, m0, 0x400\n\tv_add_u32 %1, 0x400, %1\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\ts_add_u32 m0, m0, 0x400\n\tv_add_u32 %1, 0x400, %1\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\ts_add_u32 m0, m0, 0x400\n\tv_add_u32 %1, 0x400, %1\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\ts_add_u32 m0, m0, 0x400\n\tv_add_u32 %1, 0x400, %1\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\ts_add_u32 m0, m0, 0x400\n\tv_add_u32 %1, 0x400, %1\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\ts_add_u32 m0, m0, 0x400\n\tv_add_u32 %1, 0x400, %1\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\ts_add_u32 m0, m0, 0x400\n\tv_add_u32 %1, 0x400, %1\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep), "+v"(lane_off) : "s"(gsrc_uniform), "s"(lds_addr_uniform) : "memory", "scc");
 }
-__device__ __forceinline__ void tw_dma4(const unsigned char *gsrc_lane, uint32_t lds_addr_uniform) {
+__device__ __forceinline__ void tw_dma_256(const unsigned char *gsrc_uniform, uint32_t lane_off, uint32_t lds_addr_uniform) {   // 64 x 4 B
   uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr_uniform) : "memory");
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_addr_uniform) : "memory");
 }
 
-template <int DT, int MT>
+// FAST: the 14x14 geometry (grid pitch 16 = tile height), where the row tiles of a wave are a constant
+// 4 KiB apart in the image and only the last one can cross the aliased bottom border.
+template <int DT, int MT, bool FAST>
 __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char *const img = smem;
+  unsigned char *const img = smem + TW_IMG0;
   unsigned char *const ring = smem + TW_RING;
-  const float *const biasbuf = reinterpret_cast<const float *>(smem + TW_SPARE);   // [2][256], filled by LDS-DMA
-  float *const vred = reinterpret_cast<float *>(smem + TW_SPARE + 2048);      // [4]
-  fpc_board *const lboard = reinterpret_cast<fpc_board *>(smem + TW_SPARE + 2048 + 64);
+  const float *const biasbuf = reinterpret_cast<const float *>(smem + TW_BIAS);
+  float *const vred = reinterpret_cast<float *>(smem + TW_VRED);
+  fpc_board *const lboard = reinterpret_cast<fpc_board *>(smem + TW_BOARD);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -123,7 +155,7 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
   const int game = blockIdx.x;
   const int P = g.P, NR = g.NR;
 
-  // a game that has left the search (Q5) or a slot past the batch: nothing to evaluate
+  // a game that has left the search (Q5): nothing to evaluate
   int slot = 0, rot_k = 0;
   if (g.boards) {
     slot = g.leaf_slot[game];
@@ -132,28 +164,24 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
   }
 
   // ---- per-lane geometry -------------------------------------------------------------------------
-  int r0[MT];                    // grid position (image row) of this lane in each of its row tiles
-  uint32_t inmask = 0;           // bit mt: that position is an interior square
+  const int rbase = (g.T0 + wm * MT) * 16 + li;       // grid position (image row) of this lane in its first row tile
+  uint32_t inmask = 0;                                // bit mt: the lane's position in row tile mt is an interior square
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    r0[mt] = (g.T0 + wm * MT + mt) * 16 + li;
-    const int pi = r0[mt] / P, pj = r0[mt] - pi * P;
-    if (r0[mt] < g.PP && pi >= 1 && pi <= g.R && pj >= 1 && pj <= g.R) inmask |= 1u << mt;
+    const int r = rbase + 16 * mt;
+    const int pi = r / P, pj = r - pi * P;
+    if (r < g.PP && pi >= 1 && pi <= g.R && pj >= 1 && pj <= g.R) inmask |= 1u << mt;
   }
   const int bq = (lq >> 1) * 256 + (lq & 1) * 128;                 // chunk-within-k-step part of a fragment address
   const int apart = (li >> 3) * 2048 + (li & 7) * 16 + bq;         // weight fragment: row li of a 16-row tile (CH = 16)
   const int apart_s = (li >> 3) * 512 + (li & 7) * 16 + bq;        // same for the stem's 4-chunk rows
+  const int cb64 = wn * 64, cb16 = wn * 16;                        // first output channel of this wave (conv layers / value conv)
 
   // ---- zero the image, build the stem's input image, fetch the stem's weights -----------------------
-  for (int c = tid; c < TW_IMG / 16; c += TW_THREADS) reinterpret_cast<t_u32x4 *>(img)[c] = t_u32x4{0u, 0u, 0u, 0u};
+  for (int c = tid; c < (TW_IMG0 + TW_IMG) / 16; c += TW_THREADS) reinterpret_cast<t_u32x4 *>(smem)[c] = t_u32x4{0u, 0u, 0u, 0u};
   unsigned char *const enc = smem + TW_ENC;
   const int enc_bytes = ((NR + 7) >> 3) * 512;
   for (int c = tid; c < enc_bytes / 16; c += TW_THREADS) reinterpret_cast<t_u32x4 *>(enc)[c] = t_u32x4{0u, 0u, 0u, 0u};
-  if (g.boards) {
-    constexpr int WPB = (int)(sizeof(fpc_board) / 4);
-    if (tid < WPB) reinterpret_cast<uint32_t *>(lboard)[tid] =
-        reinterpret_cast<const uint32_t *>(g.boards + (size_t)game * g.board_stride + slot)[tid];
-  }
   {  // stem weights: 72 KiB by plain 16-byte copies (once per launch)
     const t_u32x4 *src = reinterpret_cast<const t_u32x4 *>(g.Wstem);
     t_u32x4 *dst = reinterpret_cast<t_u32x4 *>(ring);
@@ -161,9 +189,13 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
   }
   t_f32x4 bst[4];
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct) bst[ct] = *reinterpret_cast<const t_f32x4 *>(g.bstem + wn * 64 + ct * 16 + 4 * lq);
+  for (int ct = 0; ct < 4; ++ct) bst[ct] = *reinterpret_cast<const t_f32x4 *>(g.bstem + cb64 + ct * 16 + 4 * lq);
   __syncthreads();
   if (g.boards) {
+    constexpr int WPB = (int)(sizeof(fpc_board) / 4);
+    if (tid < WPB) reinterpret_cast<uint32_t *>(lboard)[tid] =
+        reinterpret_cast<const uint32_t *>(g.boards + (size_t)game * g.board_stride + slot)[tid];
+    __syncthreads();
     // GetEncodedStates: plane = 6*((colour - turn) & 3) + type - 1, -1 wrapping to 23 (Q7); the whole
     // batch is rotated by the turn of the first live leaf (Q6)
     for (int r = tid; r < g.PP; r += TW_THREADS) {
@@ -184,15 +216,14 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
   }
   __syncthreads();
 
-  // Accumulators are never zeroed: the first MFMA of every layer takes C = 0 as an inline constant
+  // Accumulators are never zeroed: the first MFMA of every layer takes the layer's bias as C
   // (a zero-initialised accumulator carried into the tap loop makes hipcc rotate 100+ registers per tap).
   t_f32x4 acc[MT][4];
   t_u32x2 res[MT][4];           // residual x_l of this lane's outputs, packed 16-bit channel pairs
-  const t_f32x4 zero4 = t_f32x4{0.f, 0.f, 0.f, 0.f};
 
   // image row of this lane for row tile mt under a tap shift, bottom border aliased onto the top one
   auto brow = [&](int mt, int shift) -> int {
-    int r = r0[mt] + shift;
+    int r = rbase + 16 * mt + shift;
     r = r < 0 ? r + NR : r;
     r = r >= NR ? r - NR : r;
     return r;
@@ -205,7 +236,7 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
     t_u32x4 fa[4], fb[MT];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
-      fa[ct] = *reinterpret_cast<const t_u32x4 *>(ring + tap * TW_STEM_TAP + (wn * 64 + ct * 16) * 64 + apart_s);
+      fa[ct] = *reinterpret_cast<const t_u32x4 *>(ring + tap * TW_STEM_TAP + (cb64 + ct * 16) * 64 + apart_s);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int r = brow(mt, shift);
@@ -214,124 +245,138 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) acc[mt][ct] = M16<DT>::mfma(fa[ct], fb[mt], tap == 0 ? zero4 : acc[mt][ct]);
+      for (int ct = 0; ct < 4; ++ct) acc[mt][ct] = M16<DT>::mfma(fa[ct], fb[mt], tap == 0 ? bst[ct] : acc[mt][ct]);
   }
   __syncthreads();               // every wave is done with the stem's weights and input image
 
   // ---- weight ring ------------------------------------------------------------------------------------
   const int total = (g.L + 2) * 9;
+  const uint32_t dma_lane = (uint32_t)lane * 16u;
   auto issue_tap = [&](int gt) {   // tap gt -> ring slot gt % 3 (8 x 1 KiB per wave); first tap of a layer: + its biases
-    const unsigned char *src = g.Wt + (size_t)gt * TW_TAP + wave * 8192 + lane * 16;
-    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(TW_RING + (gt % 3) * TW_TAP + wave * 8192);   // smem starts at LDS byte 0
-#pragma unroll
-    for (int p = 0; p < 8; ++p) tw_dma16(src + p * 1024, dst + p * 1024);
+    tw_dma_8k(g.Wt + (size_t)gt * TW_TAP + wave * 8192, dma_lane,
+              (uint32_t)__builtin_amdgcn_readfirstlane(TW_RING + (gt % 3) * TW_TAP + wave * 8192));   // smem starts at LDS byte 0
     if (gt % 9 == 0) {
       const int l = gt / 9;
-      tw_dma4(reinterpret_cast<const unsigned char *>(g.bt + (size_t)l * 256 + wave * 64 + lane),
-              (uint32_t)__builtin_amdgcn_readfirstlane(TW_SPARE + ((l & 1) * 256 + wave * 64) * 4));
+      tw_dma_256(reinterpret_cast<const unsigned char *>(g.bt + (size_t)l * 256 + wave * 64), (uint32_t)lane * 4u,
+                 (uint32_t)__builtin_amdgcn_readfirstlane(TW_BIAS + ((l & 1) * 256 + wave * 64) * 4));
     }
   };
   issue_tap(0);
   issue_tap(1);
 
-  // epilogue: v = acc + bias (+ residual); ReLU; 16-bit; written IN PLACE into the image at interior
-  // squares (4 consecutive channels = one 8-byte write; other lanes write to a dummy strip, no branch)
-  unsigned char *const dummy = smem + TW_SPARE + 2560 + lane * 8;
-  auto epilogue = [&](const t_f32x4 *bias4, bool add_res, bool keep_res) {
+  // epilogue: the accumulators hold conv + bias; (+ residual, f32); 16-bit; ReLU on the packed pairs;
+  // written IN PLACE into the image at interior squares (4 consecutive channels = one 8-byte write; the
+  // other lanes write to a dummy strip, no branch)
+  unsigned char *const dummy = smem + TW_DUMMY + lane * 8;
+  unsigned char *const wbase = img + (rbase >> 3) * 2048 + (rbase & 7) * 16 + wn * 1024 + (lane >> 5) * 128 + ((lane >> 4) & 1) * 8;
+  auto epilogue = [&](auto res_c) {
+    constexpr int RES = decltype(res_c)::value;      // 0: plain; 1: keep as residual (stem); 2: add the residual, keep
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int r = r0[mt];
-      unsigned char *dst = img + (r >> 3) * 2048 + (r & 7) * 16 + wn * 1024 + (lane >> 5) * 128 + ((lane >> 4) & 1) * 8;
-      const bool in = (inmask >> mt) & 1u;
+      unsigned char *dst = ((inmask >> mt) & 1u) ? wbase + mt * 4096 : dummy;
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
-        t_f32x4 v = acc[mt][ct] + bias4[ct];
-        if (add_res) {
+        t_f32x4 v = acc[mt][ct];
+        if (RES == 2) {
           v[0] += M16<DT>::lo(res[mt][ct][0]); v[1] += M16<DT>::hi(res[mt][ct][0]);
           v[2] += M16<DT>::lo(res[mt][ct][1]); v[3] += M16<DT>::hi(res[mt][ct][1]);
         }
-        v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
-        v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
-        const t_u32x2 pk = t_u32x2{M16<DT>::pack2(v[0], v[1]), M16<DT>::pack2(v[2], v[3])};
-        if (keep_res) res[mt][ct] = pk;
-        *reinterpret_cast<t_u32x2 *>(in ? dst + ct * 256 : dummy) = pk;
+        const t_u32x2 pk = t_u32x2{tw_relu2(M16<DT>::pack2(v[0], v[1])), tw_relu2(M16<DT>::pack2(v[2], v[3]))};
+        if (RES != 0) res[mt][ct] = pk;
+        *reinterpret_cast<t_u32x2 *>(((inmask >> mt) & 1u) ? dst + ct * 256 : dst) = pk;
       }
       __builtin_amdgcn_sched_barrier(0);     // one row tile at a time: keeps the accumulator reads from piling up in VGPRs
-    }
-  };
-  epilogue(bst, false, true);    // stem: x_0 = relu(conv + b)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();               // x_0 complete, taps 0 and 1 landed
-
-  // ---- the tower: L residual convs + value conv + policy conv, 9 taps x 4 k-steps each -------------
-  // Fragments are double-buffered one k-step ahead of the MFMAs that consume them; every load below is
-  // unconditional and lands in a statically named register set.  The k-step loop is rotated by one:
-  // a layer opens with (tap 0, k-step 0) on C = 0, and the tap loop body is k-steps 1, 2, 3 of its tap
-  // followed by k-step 0 of the next one.
-  t_u32x4 fa[2][4], fb[2][MT];
-  int gt = 0;                                      // running tap index over all layers (ring slot = gt % 3)
-  int boff[MT];                                    // image byte offset of this lane's row in each row tile under the current tap's shift
-  const unsigned char *wslot;                      // this wave's weight rows in the current tap's ring slot
-  auto set_tap = [&](int tap, int cb) {
-    wslot = ring + (gt % 3) * TW_TAP + cb * 256 + apart;
-    const int shift = (tap / 3 - 1) * P + (tap % 3 - 1);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int r = brow(mt, shift);
-      boff[mt] = (r >> 3) * 2048 + (r & 7) * 16 + bq;
-    }
-  };
-  auto prefetch = [&](auto buf_c, auto ks_c) {     // fragments of k-step ks of the current tap -> buffer buf
-    constexpr int B = decltype(buf_c)::value, KS = decltype(ks_c)::value;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) fa[B][ct] = *reinterpret_cast<const t_u32x4 *>(wslot + ct * 4096 + KS * 512);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) fb[B][mt] = *reinterpret_cast<const t_u32x4 *>(img + boff[mt] + KS * 512);
-  };
-  auto load_b0 = [&]() {                           // image fragments of k-step 0 of the current tap (after an epilogue)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) fb[0][mt] = *reinterpret_cast<const t_u32x4 *>(img + boff[mt]);
-  };
-  // One k-step: the MFMAs on buffer B, with the fragment reads of k-step KSN (of the current wslot / boff)
-  // into the other buffer spread between them -- order pinned, hipcc would otherwise sink every read down
-  // to just in front of its first use and expose the LDS latency.  C = 0 when Z.
-  // MODE 0: 64 output channels per wave (4 column tiles); MODE 1 (value conv, 32 live channels): 16 per wave
-  auto kstep = [&](auto mode_c, auto buf_c, auto ksn_c, auto zero_c) {
-    constexpr int MODE = decltype(mode_c)::value, B = decltype(buf_c)::value, KSN = decltype(ksn_c)::value;
-    constexpr bool Z = decltype(zero_c)::value != 0;
-    constexpr int N = B ^ 1;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) fa[N][ct] = *reinterpret_cast<const t_u32x4 *>(wslot + ct * 4096 + KSN * 512);
-    fb[N][0] = *reinterpret_cast<const t_u32x4 *>(img + boff[0] + KSN * 512);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      if (MODE == 0) {
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[mt][ct] = M16<DT>::mfma(fa[B][ct], fb[B][mt], Z ? zero4 : acc[mt][ct]);
-      } else {
-        acc[mt][0] = M16<DT>::mfma(fa[B][0], fb[B][mt], Z ? zero4 : acc[mt][0]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (mt + 1 < MT) {
-        fb[N][mt + 1] = *reinterpret_cast<const t_u32x4 *>(img + boff[mt + 1] + KSN * 512);
-        __builtin_amdgcn_sched_barrier(0);
-      }
     }
   };
   const std::integral_constant<int, 0> c0{};
   const std::integral_constant<int, 1> c1{};
   const std::integral_constant<int, 2> c2{};
   const std::integral_constant<int, 3> c3{};
-  // One conv layer = 9 taps.  On entry fa[0] / fb[0] hold (tap 0, k-step 0) and wslot / boff are set for
-  // tap 0; on exit the same holds for the NEXT layer (whose first weight row of this wave is cb_next),
-  // except that fb[0] was read from the image the epilogue is about to rewrite (load_b0 after it).
-  auto run_layer = [&](auto mode_c, const int cb, const int cb_next) {
-    kstep(mode_c, c0, c1, c1);                     // (tap 0, k-step 0), C = 0
+  epilogue(c1);                  // stem: x_0 = relu(conv + b)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();               // x_0 complete, taps 0 and 1 (and layer 0's biases) landed
+
+  // ---- the tower: L residual convs + value conv + policy conv, 9 taps x 4 k-steps each -------------
+  // Fragments are double-buffered one k-step ahead of the MFMAs that consume them; every load below is
+  // unconditional and lands in a statically named register set.  The k-step loop is rotated by one:
+  // a layer opens with (tap 0, k-step 0) on C = bias, and the tap loop body is k-steps 1, 2, 3 of its
+  // tap followed by k-step 0 of the next one.
+  t_u32x4 fa[2][4], fb[2][MT];
+  int gt = 0;                                      // running tap index over all layers (ring slot = gt % 3)
+  const unsigned char *wslot;                      // this wave's weight rows in the current tap's ring slot
+  const unsigned char *bbase;                      // FAST: this lane's image row in its first row tile under the current shift
+  const unsigned char *blast;                      // FAST: the same for the last row tile (the only one that can cross the border alias)
+  int boff[FAST ? 1 : MT];                         // !FAST: image byte offset per row tile
+  auto set_tap = [&](int tap, int cb) {
+    wslot = ring + (gt % 3) * TW_TAP + cb * 256 + apart;
+    const int shift = (tap / 3 - 1) * P + (tap % 3 - 1);
+    if (FAST) {
+      const int r = rbase + shift;                 // >= -1; row -1 lands in the 4 KiB in front of the image
+      bbase = img + (r >> 3) * 2048 + (r & 7) * 16 + bq;
+      int rl = r + 16 * (MT - 1);
+      rl = rl >= NR ? rl - NR : rl;
+      blast = img + (rl >> 3) * 2048 + (rl & 7) * 16 + bq;
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int r = brow(mt, shift);
+        boff[mt] = (r >> 3) * 2048 + (r & 7) * 16 + bq;
+      }
+    }
+  };
+  auto bptr = [&](int mt) -> const unsigned char * {
+    if (FAST) return mt == MT - 1 ? blast : bbase + mt * 4096;
+    return img + boff[mt];
+  };
+  // One k-step: the MFMAs on buffer B, with the fragment reads of k-step KSN (of the current wslot / image
+  // rows) into the other buffer spread between them -- order pinned, hipcc would otherwise sink every
+  // read down to just in front of its first use and expose the LDS latency.
+  // MODE 0: 64 output channels per wave (4 column tiles); MODE 1 (value conv, 32 live channels): 16 per wave.
+  // BIAS: this is the layer's first k-step: C = the layer's bias instead of the accumulators.
+  auto kstep = [&](auto mode_c, auto buf_c, auto ksn_c, auto bias_c, const t_f32x4 *b4) {
+    constexpr int MODE = decltype(mode_c)::value, B = decltype(buf_c)::value, KSN = decltype(ksn_c)::value;
+    constexpr bool BIAS = decltype(bias_c)::value != 0;
+    constexpr int N = B ^ 1;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) fa[N][ct] = *reinterpret_cast<const t_u32x4 *>(wslot + ct * 4096 + KSN * 512);
+    fb[N][0] = *reinterpret_cast<const t_u32x4 *>(bptr(0) + KSN * 512);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (MODE == 0) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[mt][ct] = M16<DT>::mfma(fa[B][ct], fb[B][mt], BIAS ? b4[ct] : acc[mt][ct]);
+      } else {
+        acc[mt][0] = M16<DT>::mfma(fa[B][0], fb[B][mt], BIAS ? b4[0] : acc[mt][0]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (mt + 1 < MT) {
+        fb[N][mt + 1] = *reinterpret_cast<const t_u32x4 *>(bptr(mt + 1) + KSN * 512);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  auto load_b0 = [&]() {                           // image fragments of k-step 0 of the current tap (after an epilogue)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) fb[0][mt] = *reinterpret_cast<const t_u32x4 *>(bptr(mt));
+  };
+  // One conv layer = 9 taps.  On entry fa[0] / fb[0] hold (tap 0, k-step 0) and wslot / the image row
+  // addresses are set for tap 0; on exit the same holds for the NEXT layer (whose first weight row of
+  // this wave is cb_next), except that fb[0] was read from the image the epilogue is about to rewrite
+  // (load_b0 after it).
+  auto run_layer = [&](auto mode_c, const int layer, const int cb, const int cb_next) {
+    constexpr int MODE = decltype(mode_c)::value;
+    t_f32x4 b4[4];
+    {
+      const float *bl = biasbuf + (layer & 1) * 256 + cb + 4 * lq;
+#pragma unroll
+      for (int ct = 0; ct < (MODE == 0 ? 4 : 1); ++ct) b4[ct] = *reinterpret_cast<const t_f32x4 *>(bl + ct * 16);
+    }
+    kstep(mode_c, c0, c1, c1, b4);                 // (tap 0, k-step 0), C = bias
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
-      kstep(mode_c, c1, c2, c0);                   // k-step 1
-      kstep(mode_c, c0, c3, c0);                   // k-step 2
+      kstep(mode_c, c1, c2, c0, b4);               // k-step 1
+      kstep(mode_c, c0, c3, c0, b4);               // k-step 2
       // the next tap's weights: every wave's DMA pieces have landed, and nobody still reads the slot that
       // tap gt + 2 is about to overwrite (all waves are past tap gt - 1).  Also: all fragment reads of
       // this tap are complete, so after tap 8 the epilogue may rewrite the image in place.
@@ -340,65 +385,50 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
       if (gt + 2 < total) issue_tap(gt + 2);
       ++gt;
       set_tap(tap == 8 ? 0 : tap + 1, tap == 8 ? cb_next : cb);
-      kstep(mode_c, c1, c0, c0);                   // k-step 3, reading (next tap, k-step 0)
-      if (tap < 8) kstep(mode_c, c0, c1, c0);      // (next tap, k-step 0)
+      kstep(mode_c, c1, c0, c0, b4);               // k-step 3, reading (next tap, k-step 0)
+      if (tap < 8) kstep(mode_c, c0, c1, c0, b4);  // (next tap, k-step 0)
     }
   };
-  auto layer_bias = [&](int layer, t_f32x4 *b4) {
-    const float *bl = biasbuf + (layer & 1) * 256;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) b4[ct] = *reinterpret_cast<const t_f32x4 *>(bl + wn * 64 + ct * 16 + 4 * lq);
-  };
-  const auto mode_conv = c0;
-  const auto mode_value = c1;
-  const int cb64 = wn * 64, cb16 = wn * 16;
 
   set_tap(0, cb64);
-  prefetch(c0, c0);
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) fa[0][ct] = *reinterpret_cast<const t_u32x4 *>(wslot + ct * 4096);
+  load_b0();
   const int nblocks = g.L / 2;
 #pragma unroll 1
   for (int blk = 0; blk < nblocks; ++blk) {
-    t_f32x4 b4[4];
-    // (the barrier inside the layer's last k-step already proved that every wave has read all it needs
-    //  of the layer's input image: its last fragments were in registers before that barrier)
-    run_layer(mode_conv, cb64, cb64);                               // conv1 + BN + ReLU
-    layer_bias(2 * blk, b4);
-    epilogue(b4, false, false);
-    __syncthreads();                                                // conv2's input image is complete
+    run_layer(c0, 2 * blk, cb64, cb64);                               // conv1 + BN + ReLU
+    epilogue(c0);
+    __syncthreads();                                                  // conv2's input image is complete
     load_b0();
-    run_layer(mode_conv, cb64, blk + 1 == nblocks ? cb16 : cb64);   // conv2 + BN, + x_l, ReLU
-    layer_bias(2 * blk + 1, b4);
-    epilogue(b4, true, true);
+    run_layer(c0, 2 * blk + 1, cb64, blk + 1 == nblocks ? cb16 : cb64);   // conv2 + BN, + x_l, ReLU
+    epilogue(c2);
     __syncthreads();
     load_b0();
   }
   float vpart = 0.f;
   {
     // value head (net.py:28-35): relu(conv + b)[pos][ch] . vw[pos][ch], ch < 24 (weights, biases and vw zero-padded to 32)
-    run_layer(mode_value, cb16, cb64);
-    const t_f32x4 bv = *reinterpret_cast<const t_f32x4 *>(biasbuf + (g.L & 1) * 256 + cb16 + 4 * lq);
+    run_layer(c1, g.L, cb16, cb64);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int pi = r0[mt] / P, pj = r0[mt] - pi * P;
+      const int r = rbase + 16 * mt;
+      const int pi = r / P, pj = r - pi * P;
       const bool in = (inmask >> mt) & 1u;
       const int qp = in ? (pi - 1) * g.R + (pj - 1) : 0;
       const t_f32x4 w4 = *reinterpret_cast<const t_f32x4 *>(g.vw + qp * 32 + cb16 + 4 * lq);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float v = acc[mt][0][j] + bv[j];
+        float v = acc[mt][0][j];
         v = v > 0.f ? v : 0.f;
         vpart += in ? v * w4[j] : 0.f;
       }
     }
     // (the value conv leaves the image as it was: fb[0], read during its last k-step, is valid)
   }
-  {
-    t_f32x4 b4[4];
-    run_layer(mode_conv, cb64, cb64);                               // policy conv + BN + ReLU, 16-bit rows in place
-    layer_bias(g.L + 1, b4);
-    epilogue(b4, false, false);
-    __syncthreads();
-  }
+  run_layer(c0, g.L + 1, cb64, cb64);                                 // policy conv + BN + ReLU, 16-bit rows in place
+  epilogue(c0);
+  __syncthreads();
 
   // ---- heads: policy-conv rows -> Linear input (position-major), value -> tanh ---------------------------
   {

@@ -11,7 +11,7 @@
 // are nine row-shifted views of ONE matrix:  Y[m, co] = sum_t sum_ci X[m + off_t, ci] * W[t, co, ci]
 // -- no im2col, no bounds checks in the inner loop.  M = games*256 rows, N = Cout, K = 9*Cin.
 // Kernels: k_tower (fpc_tower.h: whole residual tower + head convs, activations LDS-resident, hidden = 128),
-// k_conv3x3 (one conv per launch, any hidden width), k_fc256 (weight-streaming policy Linear).
+// k_conv3x3 (one conv per launch, any hidden width), k_fc (fpc_fc.h: weight-streaming policy Linear).
 // All use v_mfma_f32_32x32x16_{bf16,f16} and a 16-byte-chunk XOR swizzle in LDS that makes every
 // ds_read_b128 fragment read conflict-free.
 #pragma once
@@ -57,7 +57,7 @@ struct E16<1> {  // fp16
 };
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128;
-constexpr int FC_SPLITK = 4;   // K-splits of a long policy-Linear block; short blocks use 2x (see k_fc256)
+constexpr int FC_SPLITK = 4;   // K-splits of a long policy-Linear block; short blocks use 2x (see k_fc)
 
 // byte offset of 16-B chunk j of tile row `row` (BK elements per row), XOR-swizzled so that the
 // 16-lane groups of a ds_read_b128 touch 16 distinct 16-B slots of the 256-B bank row
@@ -247,156 +247,9 @@ __global__ void __launch_bounds__(CONV_THREADS) k_conv3x3(ConvArgs g) {
   }
 }
 
-// ================================================================================================
-// k_fc256: the policy Linear (net.py:25: A -> A, 553 M weights at 14x14 = 1.1 GB in 16 bit) as a
-// weight-streaming GEMM for M = 256 rows: every weight byte is used once per forward.
-//   * W is stored by the exporter in MFMA FRAGMENT ORDER  [kstep16][n_tile32][lane 64][8 elems]
-//     (k-step major: all waves advance through K together, so what the chip reads at any moment is a
-//     few contiguous regions spread over every HBM channel instead of 736 streams 1.4 MB apart):
-//     one v_mfma_f32_32x32x16 B-operand of a wave is one contiguous, perfectly coalesced 1-KiB read
-//     that goes straight from HBM into VGPRs -- the weights never touch LDS and are never shared
-//     between waves (each wave owns 32 output columns for all 256 rows).
-//   * Only the activations X[256][K] (12 MB, L2 resident, re-read by every column group) go through
-//     LDS (2 x 32 KiB double buffer of BK = 64 stages, swizzled).  s_memtime stamps showed the waves of
-//     the 4-wave version spending 45 % of their time issuing those loads and waiting for them (the
-//     CU's one load path moved 2 bytes of X per byte of W), so a block is 8 waves = 256 columns: the
-//     X tile is fetched once per CU and stage, in full 128-byte lines, two stages ahead.
-//   * Work decomposition: column group j (256 columns) x K-split i.  Groups [0, G1) are cut into s1
-//     K-splits, the remaining groups into s2 = 2*s1 half-length ones, G1 chosen by the host so that
-//     the short blocks fill the tail of the last round (368 equal blocks on 256 CUs would idle 28 %).
-//     Block ids put the K-split in the low bits, so one XCD (id mod 8) only ever walks one K window
-//     of X and keeps it in its own L2.
-//   * Every block writes its f32 partial slab [Mtot][256]; k_fc_reduce adds a group's slabs and the
-//     bias in a fixed order (deterministic, no atomics).
-// ================================================================================================
-struct FcArgs {
-  const uint16_t *X;      // [Mpad][Kp]
-  const uint16_t *Wf;     // fragment order
-  float *part;            // [slabs][Mtot][256]
-  int Kp, Np, ksteps, Mtot;
-  int G1, s1, s2;         // groups [0,G1): s1 splits; groups [G1, Np/256): s2 splits
-};
-
-constexpr int FC_THREADS = 512;
-
-template <int DT>
-__global__ void __launch_bounds__(FC_THREADS, 1) k_fc256(FcArgs g) {
-  __shared__ __attribute__((aligned(16))) unsigned char As[2][256 * 64 * 2];   // 2 x 32 KiB
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // block id -> (column group, K-split, slab)
-  const int nbig = g.G1 * g.s1;
-  const int id = blockIdx.x;
-  const bool big = id < nbig;
-  const int idr = big ? id : id - nbig;
-  const int sk = big ? g.s1 : g.s2;
-  const int group = big ? idr / sk : g.G1 + idr / sk;
-  const int split = idr % sk;
-  const int ntile = group * 8 + wave;
-  const int KS = g.ksteps / sk;                   // k-steps (of 16) handled by this block; multiple of 8
-  const int ks0 = split * KS;
-  const int S = KS / 4;                           // stages of BK = 64 (even, >= 4)
-  const long wstride = (long)(g.Np / 32) * 64;    // u32x4 units between consecutive k-steps
-  const u32x4_t *wsrc = reinterpret_cast<const u32x4_t *>(g.Wf) + ((long)ks0 * (g.Np / 32) + ntile) * 64 + lane;
-  const long mrow0 = (long)blockIdx.y * 256;
-
-  f32x16_t acc[8];
-#pragma unroll
-  for (int t = 0; t < 8; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-  u32x4_t wq[2][4];       // weight fragments of stages s, s+1 (slot = stage parity)
-  u32x4_t ra[4];          // the activation tile of the next stage on its way global -> LDS
-  // NOTE: no conditionals around memory operations inside the steady-state loop -- a branch makes
-  // hipcc fall back to s_waitcnt vmcnt(0) at the join.  The last four stages run in a copy of the
-  // step without the loads that would run past the block's K range.
-  const uint16_t *xsrc = g.X + (mrow0 + (tid >> 3)) * g.Kp + (long)ks0 * 16 + (tid & 7) * 8;
-  const long xrow64 = 64L * g.Kp;                 // 512 threads cover 64 rows (8 lanes x 16 B = one 128-B line each) per pass
-#define FPC_ALOAD2(H_, S_)                                                                           \
-  _Pragma("unroll") for (int i = 2 * (H_); i < 2 * (H_) + 2; ++i)                                    \
-    ra[i] = *reinterpret_cast<const u32x4_t *>(xsrc + i * xrow64 + (long)(S_) * 64);
-#define FPC_ASTORE2(H_, BUF_)                                                                        \
-  _Pragma("unroll") for (int i = 2 * (H_); i < 2 * (H_) + 2; ++i)                                    \
-    *reinterpret_cast<u32x4_t *>(As[BUF_] + lds_off<64>((tid >> 3) + 64 * i, tid & 7)) = ra[i];
-#define FPC_WLOAD1(SLOT_, J_, S_) wq[SLOT_][J_] = wsrc[(long)(4 * (S_) + (J_)) * wstride];
-#define FPC_RD4(DST, KS_, T0_)                                                                       \
-  _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                      \
-    DST[q] = *reinterpret_cast<const u32x4_t *>(ab_ + lds_off<64>(((T0_) + q) * 32 + (lane & 31), (KS_) * 2 + (lane >> 5)));
-#define FPC_MM4(SRC, W_, T0_)                                                                        \
-  _Pragma("unroll") for (int q = 0; q < 4; ++q) acc[(T0_) + q] = E16<DT>::mfma(SRC[q], W_, acc[(T0_) + q]);
-#define FPC_SB __builtin_amdgcn_sched_barrier(0)
-  // One stage = 32 MFMAs on As[s&1] in 8 groups of 4.  The activation fragments are read from LDS two
-  // groups ahead of the MFMAs that consume them, and the stage's memory traffic is spread between the
-  // groups instead of being issued in one burst after them: each weight fragment is re-requested for
-  // stage s+2 right after its last use (LW_), the staged activations of stage s+1 go to the other LDS
-  // buffer behind groups 4-5 (SX_) and their registers are re-requested for stage s+2 behind groups
-  // 6-7 (LX_).  LW_/SX_/LX_ are literals: no runtime conditionals around memory operations (a branch
-  // makes hipcc fall back to s_waitcnt vmcnt(0) at the join).
-#define FPC_FCSTEP(S_, P_, LW_, SX_, LX_)                                                            \
-  {                                                                                                  \
-    const unsigned char *ab_ = As[(S_) & 1];                                                         \
-    u32x4_t fp[4], fq[4];                                                                            \
-    FPC_RD4(fp, 0, 0); FPC_RD4(fq, 0, 4); FPC_SB;                                                    \
-    FPC_MM4(fp, wq[P_][0], 0); FPC_SB; FPC_RD4(fp, 1, 0); FPC_SB;                                    \
-    FPC_MM4(fq, wq[P_][0], 4); FPC_SB; FPC_RD4(fq, 1, 4); if (LW_) FPC_WLOAD1(P_, 0, (S_) + 2); FPC_SB; \
-    FPC_MM4(fp, wq[P_][1], 0); FPC_SB; FPC_RD4(fp, 2, 0); FPC_SB;                                    \
-    FPC_MM4(fq, wq[P_][1], 4); FPC_SB; FPC_RD4(fq, 2, 4); if (LW_) FPC_WLOAD1(P_, 1, (S_) + 2); FPC_SB; \
-    FPC_MM4(fp, wq[P_][2], 0); FPC_SB; FPC_RD4(fp, 3, 0); if (SX_) FPC_ASTORE2(0, 1 - (P_)); FPC_SB; \
-    FPC_MM4(fq, wq[P_][2], 4); FPC_SB; FPC_RD4(fq, 3, 4); if (LW_) FPC_WLOAD1(P_, 2, (S_) + 2);      \
-    if (SX_) FPC_ASTORE2(1, 1 - (P_)); FPC_SB;                                                       \
-    FPC_MM4(fp, wq[P_][3], 0); FPC_SB; if (LX_) FPC_ALOAD2(0, (S_) + 2); FPC_SB;                     \
-    FPC_MM4(fq, wq[P_][3], 4); FPC_SB; if (LW_) FPC_WLOAD1(P_, 3, (S_) + 2);                         \
-    if (LX_) FPC_ALOAD2(1, (S_) + 2); FPC_SB;                                                        \
-    __syncthreads();                                                                                 \
-  }
-
-  FPC_ALOAD2(0, 0); FPC_ALOAD2(1, 0);
-  _Pragma("unroll") for (int j = 0; j < 4; ++j) { FPC_WLOAD1(0, j, 0); }
-  _Pragma("unroll") for (int j = 0; j < 4; ++j) { FPC_WLOAD1(1, j, 1); }
-  FPC_ASTORE2(0, 0); FPC_ASTORE2(1, 0);
-  FPC_ALOAD2(0, 1); FPC_ALOAD2(1, 1);
-  __syncthreads();
-  int s = 0;
-  for (; s + 4 <= S; s += 2) {
-    FPC_FCSTEP(s, 0, 1, 1, 1); FPC_FCSTEP(s + 1, 1, 1, 1, 1);
-  }
-  // last two stages (s = S-2): nothing left to fetch
-  FPC_FCSTEP(s, 0, 0, 1, 0);
-  FPC_FCSTEP(s + 1, 1, 0, 0, 0);
-#undef FPC_FCSTEP
-#undef FPC_SB
-#undef FPC_RD4
-#undef FPC_MM4
-#undef FPC_ALOAD2
-#undef FPC_ASTORE2
-#undef FPC_WLOAD1
-  const int slab = big ? id : nbig + idr;
-  float *out = g.part + ((long)slab * g.Mtot + mrow0) * 256;
-  const int n = wave * 32 + (lane & 31);
-#pragma unroll
-  for (int t = 0; t < 8; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      out[(long)m * 256 + n] = acc[t][r];
-    }
-}
-
-// logits[m][n] = bias[n] + slab[base][m][n%256] + slab[base+1][m][n%256] + ...   (fixed order)
-__global__ void __launch_bounds__(256) k_fc_reduce(const float *part, const float *bias, int G1, int s1, int s2, int Mtot, int A,
-                                                   int n_rows, float *logits) {
-  const int q = blockIdx.x * 256 + threadIdx.x;         // float4 index within a row
-  const int m = blockIdx.y;
-  if (m >= n_rows || q * 4 >= A) return;
-  const int j = q >> 6;                                 // column group of 256
-  const int base = j < G1 ? j * s1 : G1 * s1 + (j - G1) * s2, cnt = j < G1 ? s1 : s2;
-  float4 v = *reinterpret_cast<const float4 *>(bias + q * 4);
-  for (int k = 0; k < cnt; ++k) {
-    const float4 p = *reinterpret_cast<const float4 *>(part + ((long)(base + k) * Mtot + m) * 256 + (q & 63) * 4);
-    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-  }
-  *reinterpret_cast<float4 *>(logits + (long)m * A + q * 4) = v;
-}
+}  // namespace fpc
+#include "fpc_fc.h"   // k_fc + k_fc_reduce: the weight-streaming policy Linear
+namespace fpc {
 
 // ================================================================================================
 // LEGAL-ONLY policy head (opt-in, fpc_set_policy_mode(FPC_POLICY_LEGAL)).
@@ -573,7 +426,7 @@ struct NN {
   std::vector<ConvW> c1, c2;
   uint16_t *fcw = nullptr;
   float *fcb = nullptr, *vw = nullptr;
-  float *fc_part = nullptr;      // [slabs][Gpad][256] partial sums of k_fc256 (sized for 2*FC_SPLITK slabs per group)
+  float *fc_part = nullptr;      // [slabs][Gpad][256] partial sums of k_fc (sized for 2*FC_SPLITK slabs per group)
   int fc_G1 = 0, fc_s2 = FC_SPLITK;   // work decomposition chosen at load time (plan_fc)
   unsigned char *towerW = nullptr;   // k_tower's weight stream: [(2*nblocks + 2) * 9 taps][32 KiB] in LDS-image order (F == 128)
   unsigned char *stemW = nullptr;    // [9 taps][8 KiB], same order
@@ -622,7 +475,7 @@ struct NN {
   float *d_ll = nullptr;         // [Gmax][FPC_MAX_MOVES] logits of the leaves' legal moves
   float *legal_logits() { return d_ll; }
 
-  // Policy-Linear work decomposition (see k_fc256): how many column groups get FC_SPLITK long blocks,
+  // Policy-Linear work decomposition (see k_fc): how many column groups get FC_SPLITK long blocks,
   // the rest getting twice as many half-length ones, so that the last round of blocks is full.
   // Blocks are dispatched in id order, one per CU: simulate that and keep the shortest makespan.
   void plan_fc() {
@@ -805,11 +658,11 @@ struct NN {
       f.G1 = fc_G1; f.s1 = FC_SPLITK; f.s2 = fc_s2;
       const int mtiles = (n + 255) / 256;
       const int blocks = fc_G1 * FC_SPLITK + (Np / 256 - fc_G1) * fc_s2;
-      hipLaunchKernelGGL((k_fc256<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), 0, stream, f);
+      hipLaunchKernelGGL((k_fc<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), 0, stream, f);
       hipLaunchKernelGGL(k_fc_reduce, dim3((dc.A / 4 + 255) / 256, n), dim3(256), 0, stream, (const float *)fc_part, (const float *)fcb,
                          fc_G1, FC_SPLITK, fc_s2, Gpad, dc.A, n, logits_out);
       const hipError_t le = hipGetLastError();
-      if (le != hipSuccess) { *err = std::string("k_fc256 launch failed: ") + hipGetErrorString(le); return FPC_ENODEVICE; }
+      if (le != hipSuccess) { *err = std::string("k_fc launch failed: ") + hipGetErrorString(le); return FPC_ENODEVICE; }
     }
     if (!use_tower) hipLaunchKernelGGL((k_value_tail<DT>), dim3(n), dim3(64), 0, stream, (const uint16_t *)(yv + (size_t)guard * 32),
                        (const float *)vw, vb, P, dc.R, PP, n, value_out);

@@ -50,8 +50,8 @@ def export_weights(model, dtype=0):
     RR = A // A_ch
     R = int(round(RR ** 0.5))
     assert R * R == RR and fc.weight.shape[1] == A
-    Np = (A + 255) // 256 * 256          # k_fc256 blocks own 256 columns
-    Kp = (A + 511) // 512 * 512      # k_fc256: K/16 k-steps, split-K 4 (8 for the short blocks), 4 k-steps per stage, stages in pairs
+    Np = (A + 255) // 256 * 256          # k_fc blocks own 256 columns
+    Kp = (A + 511) // 512 * 512      # k_fc: K/16 k-steps, split-K 4 (8 for the short blocks), 4 k-steps per stage, stages in pairs
     secs = []
     w, b = _fold(model.startBlock[0], model.startBlock[1])
     Fp = (F + 127) // 128 * 128
@@ -71,7 +71,7 @@ def export_weights(model, dtype=0):
     fwp = torch.zeros(Np, Kp, dtype=t16)
     fwp[:A, :A] = fw.to(t16)
     del fw
-    # MFMA fragment order (csrc/fpc_nn.h k_fc256): [kstep16][n_tile32][lane = 32*h + r][8],
+    # MFMA fragment order (csrc/fpc_nn.h k_fc): [kstep16][n_tile32][lane = 32*h + r][8],
     # element (ks, nt, h, r, e) = W'[nt*32 + r][ks*16 + h*8 + e]
     wf = fwp.view(Np // 32, 32, Kp // 16, 2, 8).permute(2, 0, 3, 1, 4).contiguous()
     del fwp

@@ -12,9 +12,11 @@
 //     from LDS feeds two MFMAs (0.5 KiB of LDS per MFMA; the 8-wave / 32-column version of round 1 paid
 //     1 KiB and stalled on the LDS queue), and the fragment reads run a whole k-step (16 MFMAs, 512
 //     cycles) ahead of their use.
-//   * Only the activations X[256][K] (12 MB, L2 resident, re-read by every column group) go through
-//     LDS (2 x 32 KiB double buffer of BK = 64 stages, XOR-swizzled), fetched in full 128-byte lines
-//     two stages ahead through registers.
+//   * Both operands arrive by LDS-DMA (global_load_lds_dwordx4, no VGPR hop): the activations X[256][K]
+//     (12 MB, L2 resident, re-read by every column group) in full 128-byte lines into three 32 KiB stage
+//     buffers shared by the block (XOR-swizzled through the source address), the weights into a private
+//     16 KiB ring per wave from which each lane reads back exactly the 16 bytes it stored.  Both streams
+//     run two stages ahead (64 KiB of weights in flight per CU).
 //   * Work decomposition: column group j (256 columns) x K-split i.  Groups [0, G1) are cut into s1
 //     K-splits, the remaining groups into s2 = 2*s1 half-length ones, G1 chosen by the host so that
 //     the short blocks fill the tail of the last round (368 equal blocks on 256 CUs would idle 28 %).
@@ -22,9 +24,7 @@
 //     of X and keeps it in its own L2.
 //   * Every block writes its f32 partial slab [Mtot][256]; k_fc_reduce adds a group's slabs and the
 //     bias in a fixed order (deterministic, no atomics).
-//   * No runtime conditionals surround memory operations in the steady-state loop (hipcc would fall back
-//     to s_waitcnt vmcnt(0) at the join); the first and the last two stages are separate copies of the
-//     stage body.  The first MFMA on every accumulator takes C = 0 as an inline constant.
+//   * The first MFMA on every accumulator takes C = 0 as an inline constant.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -41,10 +41,22 @@ struct FcArgs {
 };
 
 constexpr int FC_THREADS = 256;
+constexpr int FC_XBUF = 256 * 64 * 2;             // one BK = 64 stage of activations: 32 KiB
+constexpr int FC_WRING = 16 * 1024;               // per wave: 2 stages x 4 k-steps x 2 column tiles x 1 KiB
+constexpr int FC_LDS = 3 * FC_XBUF + 4 * FC_WRING;   // 163840: the whole LDS of a CU
+
+// one 1-KiB LDS-DMA piece (64 lanes x 16 B): global (SGPR base + per-lane byte offset) -> LDS, no VGPR
+// destination.  Inline asm on purpose: every wait for these pieces is an explicit counted s_waitcnt in
+// k_fc.  M0 carries the wave-uniform LDS byte address and is restored inside the statement.
+__device__ __forceinline__ void fc_dma(const void *gsrc_uniform, uint32_t lane_off, uint32_t lds_addr_uniform) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_addr_uniform) : "memory");
+}
 
 template <int DT>
 __global__ void __launch_bounds__(FC_THREADS, 1) k_fc(FcArgs g) {
-  __shared__ __attribute__((aligned(16))) unsigned char As[2][256 * 64 * 2];   // 2 x 32 KiB
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [3 X buffers][4 per-wave weight rings]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // block id -> (column group, K-split, slab)
@@ -59,17 +71,27 @@ __global__ void __launch_bounds__(FC_THREADS, 1) k_fc(FcArgs g) {
   const int KS = g.ksteps / sk;                   // k-steps (of 16) handled by this block; multiple of 8
   const int ks0 = split * KS;
   const int S = KS / 4;                           // stages of BK = 64 (even, >= 4)
-  const long wstride = (long)(g.Np / 32) * 64;    // u32x4 units between consecutive k-steps
-  const u32x4_t *wsrc = reinterpret_cast<const u32x4_t *>(g.Wf) + ((long)ks0 * (g.Np / 32) + ntile) * 64 + lane;
   const long mrow0 = (long)blockIdx.y * 256;
-  // activation staging: 256 threads cover 32 rows (8 lanes x 16 B = one 128-byte line each) per pass, 8 passes
-  const uint16_t *xsrc = g.X + (mrow0 + (tid >> 3)) * g.Kp + (long)ks0 * 16 + (tid & 7) * 8;
-  const long xrow32 = 32L * g.Kp;
+  // weight stream of this wave: fragment (k-step k, tile ntile + n) = 1 KiB at wbase + (k * Np/32 + n) KiB
+  const unsigned char *wbase = reinterpret_cast<const unsigned char *>(g.Wf) + ((long)ks0 * (g.Np / 32) + ntile) * 1024;
+  const long wkstep = (long)(g.Np / 32) * 1024;
+  const uint32_t wlane = (uint32_t)lane * 16u;
+  // activation staging: this wave brings rows [64 wave, 64 wave + 64) of every stage: 8 pieces of 8 rows x
+  // 128 B (full lines).  The LDS image is XOR-swizzled (lds_off<64>); a DMA piece lands lane-linear, so
+  // the swizzle goes on the SOURCE: LDS slot (row, c) must receive logical chunk c ^ ((row >> 1) & 7).
+  const unsigned char *xbase = reinterpret_cast<const unsigned char *>(g.X) + ((mrow0 + wave * 64) * g.Kp + (long)ks0 * 16) * 2;
+  const long xpiece = 8L * g.Kp * 2;              // bytes between consecutive pieces (8 rows)
+  uint32_t xlane[2];                              // per-lane source offset for even / odd pieces
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int j = (lane & 7) ^ ((par * 4 + (lane >> 4)) & 7);
+    xlane[par] = (uint32_t)((lane >> 3) * g.Kp * 2 + j * 16);
+  }
+  const uint32_t lds_x = 0, lds_w = (uint32_t)(3 * FC_XBUF + wave * FC_WRING);
+  const unsigned char *wr = smem + 3 * FC_XBUF + wave * FC_WRING + lane * 16;   // this lane's 16 B of a ring fragment
 
   f32x16_t acc[8][2];
-  u32x4_t wq[2][4][2];    // weight fragments of stages s, s+1 (slot = stage parity) [k-step][column tile]
-  u32x4_t ra[8];          // the activation tile of the next stage on its way global -> LDS
-  u32x4_t xf[2][8];       // activation fragments of the current / the next k-step
+  u32x4_t xf[2][8], wf[2][2];   // activation / weight fragments of the current and the next k-step
   const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   const std::integral_constant<int, 0> c0{};
@@ -77,79 +99,95 @@ __global__ void __launch_bounds__(FC_THREADS, 1) k_fc(FcArgs g) {
   const std::integral_constant<int, 2> c2{};
   const std::integral_constant<int, 3> c3{};
 
-  auto xload = [&](int i, int s) { ra[i] = *reinterpret_cast<const u32x4_t *>(xsrc + i * xrow32 + (long)s * 64); };
-  auto xstore = [&](int i, int buf) {
-    *reinterpret_cast<u32x4_t *>(As[buf] + lds_off<64>((tid >> 3) + 32 * i, tid & 7)) = ra[i];
+  // DMA issue.  Stage indices past the end are clamped: the stream then re-reads the last stage into
+  // slots nobody reads any more, which keeps the issue pattern -- and with it every vmcnt count below --
+  // the same from the first to the last stage.
+  auto issue_x = [&](int s, int p) {              // piece p (8 rows) of activation stage s
+    const int sc = s < S ? s : S - 1;
+    fc_dma(xbase + (long)p * xpiece + (long)sc * 128, xlane[p & 1],
+           (uint32_t)__builtin_amdgcn_readfirstlane(lds_x + (s % 3) * FC_XBUF + (wave * 64 + p * 8) * 128));
   };
-  auto wload = [&](int p, int ks, int n, int s) { wq[p][ks][n] = wsrc[(long)(4 * s + ks) * wstride + n * 64]; };
+  auto issue_w = [&](int s, int ks) {             // both column tiles of k-step ks of stage s
+    const int sc = s < S ? s : S - 1;
+    const unsigned char *src = wbase + (long)(4 * sc + ks) * wkstep;
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(lds_w + ((s & 1) * 8 + ks * 2) * 1024);
+    fc_dma(src, wlane, dst);
+    fc_dma(src + 1024, wlane, dst + 1024);
+  };
   auto xfrag = [&](int b, int t, const unsigned char *ab, int ks) {
     xf[b][t] = *reinterpret_cast<const u32x4_t *>(ab + lds_off<64>(t * 32 + (lane & 31), ks * 2 + (lane >> 5)));
   };
+  auto wfrag = [&](int b, int s, int ks) {
+    wf[b][0] = *reinterpret_cast<const u32x4_t *>(wr + ((s & 1) * 8 + ks * 2) * 1024);
+    wf[b][1] = *reinterpret_cast<const u32x4_t *>(wr + ((s & 1) * 8 + ks * 2 + 1) * 1024);
+  };
 
-  // One k-step of stage s (parity P): 16 MFMAs on xf[KS & 1] in 8 groups of 2 (one row tile x two column
-  // tiles), the activation fragments of the NEXT k-step read between the groups, and this k-step's share
-  // of the stage's memory traffic placed behind its groups -- order pinned with sched_barrier:
-  //   LW: the two weight fragments of this k-step are re-requested for stage s + 2 right after their last use;
-  //   SX (k-steps 0, 1): the staged activations of stage s + 1 go to the other LDS buffer, four 16-byte writes each;
-  //   LX: each of those registers is re-requested for stage s + 2 right behind its write (a whole stage of flight);
-  //   k-step 3 opens with THE stage barrier: every wave has written its share of stage s + 1 and has all
-  //   its fragments of stage s in registers, so the next k-step's fragments come from the other buffer
-  //   and the buffer of stage s may be overwritten during stage s + 1.
-  auto kstep = [&](auto p_c, auto ks_c, auto z_c, auto lw_c, auto sx_c, auto lx_c, int s) {
-    constexpr int P = decltype(p_c)::value, KSI = decltype(ks_c)::value;
-    constexpr bool Z = decltype(z_c)::value != 0, LW = decltype(lw_c)::value != 0, SX = decltype(sx_c)::value != 0,
-                   LX = decltype(lx_c)::value != 0;
+  // One k-step of stage s: 16 MFMAs on xf / wf [KSI & 1] in 8 groups of 2 (one row tile x two column
+  // tiles) with the fragment reads of the NEXT k-step spread between the groups (order pinned), then
+  // this k-step's share of the stream two stages ahead:
+  //   k-steps 0, 1: four activation pieces of stage s + 2 each (buffer (s + 2) % 3, free since the barrier
+  //                 of stage s - 1); every k-step: the two weight fragments (s + 2, KSI) into the ring slots
+  //                 that (s, KSI) just vacated.
+  // Both streams run the SAME two stages ahead on purpose: vmcnt retires in issue order, so waiting for a
+  // young activation piece would otherwise force every older, deeper weight fragment to have landed and
+  // cut the weight prefetch to a fraction of its ring (that is what held round 1's kernel at 4 TB/s).
+  // Issue pattern per stage: 6, 6, 2, 2 pieces.  Counted waits (pieces issued after the one needed):
+  //   before reading the weights of (s, KSI + 1), issued at (s - 2, KSI + 1): 20 / 24 / 28 for KSI = 0 / 1 / 2;
+  //   k-step 3: the activations of stage s + 1 (last piece issued at (s - 1, 1)) and the weights of (s + 1, 0):
+  //   20, then THE stage barrier -- every wave's pieces of stage s + 1 have landed and every wave has its
+  //   last fragments of stage s in registers.
+  auto kstep = [&](auto ks_c, auto z_c, int s) {
+    constexpr int KSI = decltype(ks_c)::value;
+    constexpr bool Z = decltype(z_c)::value != 0;
     constexpr int CUR = KSI & 1, NXT = CUR ^ 1;
-    if (KSI == 3) __syncthreads();
-    const unsigned char *ab = KSI == 3 ? As[P ^ 1] : As[P];
+    if (KSI == 0) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    if (KSI == 1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    if (KSI == 2) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+    if (KSI == 3) { asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); __syncthreads(); }
+    const unsigned char *ab = smem + ((KSI == 3 ? s + 1 : s) % 3) * FC_XBUF;
     constexpr int KSN = KSI == 3 ? 0 : KSI + 1;
+    __builtin_amdgcn_sched_barrier(0);
+    wfrag(NXT, KSI == 3 ? s + 1 : s, KSN);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      acc[t][0] = E16<DT>::mfma(xf[CUR][t], wq[P][KSI][0], Z ? zero16 : acc[t][0]);
-      acc[t][1] = E16<DT>::mfma(xf[CUR][t], wq[P][KSI][1], Z ? zero16 : acc[t][1]);
+      acc[t][0] = E16<DT>::mfma(xf[CUR][t], wf[CUR][0], Z ? zero16 : acc[t][0]);
+      acc[t][1] = E16<DT>::mfma(xf[CUR][t], wf[CUR][1], Z ? zero16 : acc[t][1]);
       __builtin_amdgcn_sched_barrier(0);
       xfrag(NXT, t, ab, KSN);
-      if (SX && KSI < 2 && (t & 1)) {
-        xstore(KSI * 4 + (t >> 1), P ^ 1);
-        if (LX) xload(KSI * 4 + (t >> 1), s + 2);
-      }
-      if (LW && t == 7) { wload(P, KSI, 0, s + 2); wload(P, KSI, 1, s + 2); }
+      if (KSI < 2 && (t & 1)) issue_x(s + 2, KSI * 4 + (t >> 1));
+      if (t == 7) issue_w(s + 2, KSI);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto stage = [&](auto p_c, auto z_c, auto lw_c, auto sx_c, auto lx_c, int s) {
-    kstep(p_c, c0, z_c, lw_c, sx_c, lx_c, s);
-    kstep(p_c, c1, c0, lw_c, sx_c, lx_c, s);
-    kstep(p_c, c2, c0, lw_c, sx_c, lx_c, s);
-    kstep(p_c, c3, c0, lw_c, sx_c, lx_c, s);
-  };
 
-  // prologue: stage 0 of X into LDS, stage 1 into registers, weights of stages 0 and 1, fragments of (0, 0)
+  // prologue: stages 0 and 1 of both streams, then the fragments of (0, 0)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) xload(i, 0);
+  for (int p = 0; p < 8; ++p) issue_x(0, p);
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) { wload(0, ks, 0, 0); wload(0, ks, 1, 0); }
+  for (int ks = 0; ks < 4; ++ks) issue_w(0, ks);
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) { wload(1, ks, 0, 1); wload(1, ks, 1, 1); }
+  for (int p = 0; p < 8; ++p) issue_x(1, p);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) xstore(i, 0);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) xload(i, 1);
+  for (int ks = 0; ks < 4; ++ks) issue_w(1, ks);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < 8; ++t) xfrag(0, t, As[0], 0);
+  for (int t = 0; t < 8; ++t) xfrag(0, t, smem, 0);
+  wfrag(0, 0, 0);
 
-  stage(c0, c1, c1, c1, c1, 0);                   // first stage: C = 0 on the first k-step
-  stage(c1, c0, c1, c1, c1, 1);
-  int s = 2;
+  kstep(c0, c1, 0);                               // (0, 0): C = 0
+  kstep(c1, c0, 0);
+  kstep(c2, c0, 0);
+  kstep(c3, c0, 0);
 #pragma unroll 1
-  for (; s + 4 <= S; s += 2) {
-    stage(c0, c0, c1, c1, c1, s);
-    stage(c1, c0, c1, c1, c1, s + 1);
+  for (int s = 1; s < S; ++s) {
+    kstep(c0, c0, s);
+    kstep(c1, c0, s);
+    kstep(c2, c0, s);
+    kstep(c3, c0, s);
   }
-  stage(c0, c0, c0, c1, c0, s);                   // last two stages: nothing left to fetch
-  stage(c1, c0, c0, c0, c0, s + 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail pieces: nothing may still target LDS at exit
 
   const int slab = big ? id : nbig + idr;
   float *out = g.part + ((long)slab * g.Mtot + mrow0) * 256;

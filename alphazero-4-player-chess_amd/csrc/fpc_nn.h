@@ -436,7 +436,7 @@ struct NN {
   void *mark_ctx = nullptr;
   float vb = 0.f;
   // dynamic-LDS opt-ins (hipFuncSetAttribute) already made for this engine's device
-  bool attr_conv[2][3] = {{false, false, false}, {false, false, false}}, attr_tower[2] = {false, false}, attr_gemv = false;
+  bool attr_conv[2][3] = {{false, false, false}, {false, false, false}}, attr_tower[2] = {false, false}, attr_fc[2] = {false, false}, attr_gemv = false;
 
   template <class T>
   int dmalloc(T **p, size_t count, std::string *err) {
@@ -658,7 +658,9 @@ struct NN {
       f.G1 = fc_G1; f.s1 = FC_SPLITK; f.s2 = fc_s2;
       const int mtiles = (n + 255) / 256;
       const int blocks = fc_G1 * FC_SPLITK + (Np / 256 - fc_G1) * fc_s2;
-      hipLaunchKernelGGL((k_fc<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), 0, stream, f);
+      bool &fattr = attr_fc[DT];
+      if (!fattr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fc<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS); fattr = true; }
+      hipLaunchKernelGGL((k_fc<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), FC_LDS, stream, f);
       hipLaunchKernelGGL(k_fc_reduce, dim3((dc.A / 4 + 255) / 256, n), dim3(256), 0, stream, (const float *)fc_part, (const float *)fcb,
                          fc_G1, FC_SPLITK, fc_s2, Gpad, dc.A, n, logits_out);
       const hipError_t le = hipGetLastError();

@@ -18,6 +18,8 @@
 #include <vector>
 
 #ifndef FPC_EMUL
+#include <dlfcn.h>
+
 #include "fpc_nn.h"
 #endif
 
@@ -57,6 +59,17 @@ struct fpc_engine {
   int *d_rc_meta = nullptr;       // [max_games][3]
   size_t rc_cap = 0;
   long sims_issued = 0;           // simulation steps since fpc_search_begin (bounded by max_sims: pools + log table)
+  // ---- training tuples (device resident until the episode ends) and their RCCL exchange
+  fpc_tuple *d_tuples = nullptr;
+  int tuple_cap = 0, tuple_count = 0;
+  int *d_tgame = nullptr;           // [max_games] game ids of one collect / set_z call
+  float *d_tz = nullptr;            // [2][max_games]
+  void *comm = nullptr;             // ncclComm_t
+  int comm_rank = 0, comm_world = 1;
+  fpc_tuple *d_gather = nullptr;    // [world][gather_stride]
+  long long *d_gcounts = nullptr;   // [world + 1]: all-gathered counts; slot [world] = this rank's send value
+  int gather_stride = 0, gather_cap = 0;
+  std::vector<int> gather_counts;
   // ---- stats
   bool timing = false;
   int policy_mode = 0;            // FPC_POLICY_FULL / FPC_POLICY_LEGAL (fpc_search_run only)
@@ -212,7 +225,7 @@ void resolve_marks(fpc_engine *e) {
 
 extern "C" {
 
-int fpc_abi_version(void) { return 3; }
+int fpc_abi_version(void) { return 4; }
 
 const char *fpc_last_error(const fpc_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
@@ -346,6 +359,7 @@ int fpc_create(const fpc_config *cfg, fpc_engine **out) {
 void fpc_destroy(fpc_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->cfg.device);
+  (void)fpc_comm_destroy(e);
 #ifndef FPC_EMUL
   e->nn.destroy();
 #endif
@@ -611,6 +625,221 @@ int fpc_nn_forward(fpc_engine *e, const float *enc_dev, int n, float *logits_dev
   if (!e->nn.loaded) return fail(e, FPC_EWEIGHTS, "fpc_load_weights has not been called");
   if (n < 1 || n > e->cfg.max_games) return fail(e, FPC_EINVAL, "n out of range");
   return e->nn.forward_external(enc_dev, n, logits_dev, value_dev, &e->err);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// training tuples
+int fpc_tuples_reserve(fpc_engine *e, int capacity) {
+  if (!e || capacity < 0) return fail(e, FPC_EINVAL, "bad argument");
+  USE_DEV(e);
+  if (e->d_tuples) {
+    (void)hipFree(e->d_tuples);
+    e->allocs.erase(std::find(e->allocs.begin(), e->allocs.end(), (void *)e->d_tuples));
+    e->d_tuples = nullptr;
+  }
+  e->tuple_cap = e->tuple_count = 0;
+  int r;
+  if (capacity > 0 && (r = dalloc(e, &e->d_tuples, (size_t)capacity))) return r;
+  if (!e->d_tgame && ((r = dalloc(e, &e->d_tgame, (size_t)e->cfg.max_games)) || (r = dalloc(e, &e->d_tz, (size_t)2 * e->cfg.max_games)))) return r;
+  e->tuple_cap = capacity;
+  return 0;
+}
+
+int fpc_tuples_reset(fpc_engine *e) {
+  if (!e) return FPC_EINVAL;
+  e->tuple_count = 0;
+  return 0;
+}
+
+int fpc_collect_tuples(fpc_engine *e, const int *game_id, int ply) {
+  if (!e || !e->searching) return fail(e, FPC_ESTATE, "fpc_search_begin has not been called");
+  USE_DEV(e);
+  const int G = e->G;
+  if (e->tuple_count + G > e->tuple_cap) return fail(e, FPC_ECAPACITY, "tuple buffer full (%d + %d > %d): fpc_tuples_reserve", e->tuple_count, G, e->tuple_cap);
+  if (game_id) HIPCHK(e, hipMemcpyAsync(e->d_tgame, game_id, (size_t)G * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  FPC_LAUNCH(k_collect_tuples, G, 64, e->stream, e->t, G, game_id ? (const int *)e->d_tgame : (const int *)nullptr, ply, e->d_tuples + e->tuple_count);
+  HIPCHK(e, hipGetLastError());
+  if (game_id) HIPCHK(e, hipStreamSynchronize(e->stream));     // the caller may reuse game_id
+  e->tuple_count += G;
+  return 0;
+}
+
+int fpc_tuples_set_z(fpc_engine *e, const int *game_id, const float *z_team0, const float *z_team1, int n) {
+  if (!e || !game_id || !z_team0 || !z_team1 || n < 0) return fail(e, FPC_EINVAL, "bad argument");
+  if (n > e->cfg.max_games) return fail(e, FPC_EINVAL, "more games than max_games in one fpc_tuples_set_z call");
+  if (n == 0 || e->tuple_count == 0) return 0;
+  USE_DEV(e);
+  HIPCHK(e, hipMemcpyAsync(e->d_tgame, game_id, (size_t)n * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->d_tz, z_team0, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->d_tz + e->cfg.max_games, z_team1, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  FPC_LAUNCH(k_tuples_set_z, (e->tuple_count + 255) / 256, 256, e->stream, e->d_tuples, e->tuple_count, (const int *)e->d_tgame,
+             (const float *)e->d_tz, (const float *)(e->d_tz + e->cfg.max_games), n);
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+int fpc_tuples_count(fpc_engine *e) { return e ? e->tuple_count : FPC_EINVAL; }
+
+int fpc_tuples_read(fpc_engine *e, fpc_tuple *host_out, int first, int n) {
+  if (!e || !host_out || first < 0 || n < 0 || first + n > e->tuple_count) return fail(e, FPC_EINVAL, "bad tuple range");
+  if (n == 0) return 0;
+  USE_DEV(e);
+  HIPCHK(e, hipMemcpyAsync(host_out, e->d_tuples + first, (size_t)n * sizeof(fpc_tuple), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RCCL (backend "nccl" on ROCm), bound at run time: the copy PyTorch-ROCm already mapped into the
+// process is preferred (one HIP runtime, one RCCL), else the system librccl.so.
+#ifndef FPC_EMUL
+namespace {
+struct Rccl {
+  typedef int (*get_id_t)(void *);
+  typedef int (*allgather_t)(const void *, void *, size_t, int, void *, hipStream_t);
+  typedef int (*destroy_t)(void *);
+  typedef const char *(*errstr_t)(int);
+  void *h = nullptr;
+  get_id_t get_id = nullptr;
+  void *init_rank = nullptr;
+  allgather_t allgather = nullptr;
+  destroy_t destroy = nullptr;
+  errstr_t errstr = nullptr;
+  std::string err;
+};
+struct Id128 { char b[128]; };    // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128), passed by value
+
+Rccl &rccl() {
+  static Rccl r;
+  if (r.h || !r.err.empty()) return r;
+  const char *names[] = {"librccl.so", "librccl.so.1"};
+  for (const char *n : names) if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+  for (const char *n : names) if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  if (!r.h) r.h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!r.h) { r.err = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return r; }
+  r.get_id = (Rccl::get_id_t)dlsym(r.h, "ncclGetUniqueId");
+  r.init_rank = dlsym(r.h, "ncclCommInitRank");
+  r.allgather = (Rccl::allgather_t)dlsym(r.h, "ncclAllGather");
+  r.destroy = (Rccl::destroy_t)dlsym(r.h, "ncclCommDestroy");
+  r.errstr = (Rccl::errstr_t)dlsym(r.h, "ncclGetErrorString");
+  if (!r.get_id || !r.init_rank || !r.allgather || !r.destroy) r.err = "librccl.so lacks ncclGetUniqueId/CommInitRank/AllGather/CommDestroy";
+  return r;
+}
+int comm_fail(fpc_engine *e, const char *what, int rc) {
+  Rccl &r = rccl();
+  return fail(e, FPC_ECOMM, "%s failed: ncclResult %d (%s)", what, rc, r.errstr ? r.errstr(rc) : "?");
+}
+}  // namespace
+#endif
+
+int fpc_comm_unique_id(void *id128) {
+  if (!id128) return FPC_EINVAL;
+#ifdef FPC_EMUL
+  return fail(nullptr, FPC_EUNSUPPORTED, "RCCL exists only in the gfx950 build");
+#else
+  Rccl &r = rccl();
+  if (!r.err.empty()) return fail(nullptr, FPC_ECOMM, "%s", r.err.c_str());
+  const int rc = r.get_id(id128);
+  return rc ? comm_fail(nullptr, "ncclGetUniqueId", rc) : 0;
+#endif
+}
+
+int fpc_comm_init(fpc_engine *e, const void *id128, int rank, int world) {
+  if (!e || !id128 || world < 1 || rank < 0 || rank >= world) return fail(e, FPC_EINVAL, "bad argument");
+#ifdef FPC_EMUL
+  return fail(e, FPC_EUNSUPPORTED, "RCCL exists only in the gfx950 build");
+#else
+  USE_DEV(e);
+  Rccl &r = rccl();
+  if (!r.err.empty()) return fail(e, FPC_ECOMM, "%s", r.err.c_str());
+  if (e->comm) return fail(e, FPC_ESTATE, "communicator already initialised");
+  Id128 id;
+  memcpy(&id, id128, sizeof(id));
+  typedef int (*init_fn)(void **, int, Id128, int);
+  const int rc = ((init_fn)r.init_rank)(&e->comm, world, id, rank);
+  if (rc) { e->comm = nullptr; return comm_fail(e, "ncclCommInitRank", rc); }
+  e->comm_rank = rank; e->comm_world = world;
+  int rr;
+  if ((rr = dalloc(e, &e->d_gcounts, (size_t)world + 1))) return rr;
+  e->gather_counts.assign(world, 0);
+  return 0;
+#endif
+}
+
+int fpc_comm_destroy(fpc_engine *e) {
+  if (!e) return FPC_EINVAL;
+#ifndef FPC_EMUL
+  if (e->comm) {
+    (void)hipSetDevice(e->cfg.device);
+    (void)rccl().destroy(e->comm);
+    e->comm = nullptr;
+  }
+#endif
+  return 0;
+}
+
+int fpc_allgather_tuples(fpc_engine *e, int *counts_out, int *total_out) {
+  if (!e || !counts_out || !total_out) return fail(e, FPC_EINVAL, "bad argument");
+#ifdef FPC_EMUL
+  return fail(e, FPC_EUNSUPPORTED, "RCCL exists only in the gfx950 build");
+#else
+  if (!e->comm) return fail(e, FPC_ESTATE, "fpc_comm_init has not been called");
+  USE_DEV(e);
+  Rccl &r = rccl();
+  const int W = e->comm_world;
+  // 1. counts: every rank contributes one int64
+  long long mine = e->tuple_count;
+  HIPCHK(e, hipMemcpyAsync(e->d_gcounts + W, &mine, sizeof(mine), hipMemcpyHostToDevice, e->stream));
+  int rc = r.allgather(e->d_gcounts + W, e->d_gcounts, 1, /*ncclInt64*/ 4, e->comm, e->stream);
+  if (rc) return comm_fail(e, "ncclAllGather(counts)", rc);
+  std::vector<long long> cnt(W);
+  HIPCHK(e, hipMemcpyAsync(cnt.data(), e->d_gcounts, (size_t)W * sizeof(long long), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  long long mx = 1;
+  for (int i = 0; i < W; ++i) mx = std::max(mx, cnt[i]);
+  if (mx > e->tuple_cap) {     // the send buffer must hold the padded count
+    return fail(e, FPC_ECAPACITY, "another rank holds %lld tuples, more than this engine's tuple capacity %d (reserve the same capacity on every rank)", mx, e->tuple_cap);
+  }
+  // 2. payload, padded to the largest count: ONE collective per episode (latency-bound)
+  if ((long long)W * mx > e->gather_cap) {
+    if (e->d_gather) { (void)hipFree(e->d_gather); e->allocs.erase(std::find(e->allocs.begin(), e->allocs.end(), (void *)e->d_gather)); e->d_gather = nullptr; }
+    e->gather_cap = 0;
+    int rr;
+    if ((rr = dalloc(e, &e->d_gather, (size_t)W * mx))) return rr;
+    e->gather_cap = (int)(W * mx);
+  }
+  e->gather_stride = (int)mx;
+  rc = r.allgather(e->d_tuples, e->d_gather, (size_t)mx * sizeof(fpc_tuple), /*ncclUint8*/ 1, e->comm, e->stream);
+  if (rc) return comm_fail(e, "ncclAllGather(tuples)", rc);
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  int total = 0;
+  for (int i = 0; i < W; ++i) { e->gather_counts[i] = (int)cnt[i]; counts_out[i] = (int)cnt[i]; total += (int)cnt[i]; }
+  *total_out = total;
+  return 0;
+#endif
+}
+
+int fpc_gathered_read(fpc_engine *e, fpc_tuple *host_out, int first, int n) {
+  if (!e || !host_out || first < 0 || n < 0) return fail(e, FPC_EINVAL, "bad argument");
+#ifdef FPC_EMUL
+  return fail(e, FPC_EUNSUPPORTED, "RCCL exists only in the gfx950 build");
+#else
+  if (!e->d_gather) return fail(e, FPC_ESTATE, "fpc_allgather_tuples has not been called");
+  USE_DEV(e);
+  // logical index -> (rank, local index): ranks are stored max-padded
+  int r = 0, base = 0, i = first, left = n;
+  fpc_tuple *dst = host_out;
+  while (left > 0) {
+    while (r < e->comm_world && i >= base + e->gather_counts[r]) { base += e->gather_counts[r]; ++r; }
+    if (r >= e->comm_world) return fail(e, FPC_EINVAL, "gathered tuple range out of bounds");
+    const int loc = i - base, take = std::min(left, e->gather_counts[r] - loc);
+    HIPCHK(e, hipMemcpyAsync(dst, e->d_gather + (size_t)r * e->gather_stride + loc, (size_t)take * sizeof(fpc_tuple), hipMemcpyDeviceToHost, e->stream));
+    dst += take; i += take; left -= take;
+  }
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return 0;
 #endif
 }
 

@@ -766,6 +766,38 @@ __global__ void __launch_bounds__(64) k_root_children(Tree t, int G, int maxc, i
   if (lane == 0) { meta[g * 3 + 0] = t.N[nb]; meta[g * 3 + 1] = nc; meta[g * 3 + 2] = t.sims_done[g]; }
 }
 
+// training tuples (alphazero.py:104-112): root mailbox + side to move + sparse pi of a finished search
+__global__ void __launch_bounds__(64) k_collect_tuples(Tree t, int G, const int *game_id, int ply, fpc_tuple *out) {
+  const int g = blockIdx.x;
+  if (g >= G) return;
+  const int lane = lane_id();
+  fpc_tuple *rec = out + g;
+  const fpc_board *root = &t.boards[(size_t)g * t.board_cap];
+  const size_t nb = (size_t)g * t.node_cap;
+  const int c0 = t.child0[nb], nc = c0 < 0 ? 0 : (int)t.nch[nb];
+  for (int i = lane; i < FPC_MAX_SQ; i += 64) rec->sq[i] = root->sq[i];
+  for (int k = lane; k < FPC_TUPLE_MAXC; k += 64) {
+    const bool in = k < nc;
+    rec->flat[k] = in ? t.mv[nb + c0 + k] : (uint16_t)0;
+    rec->visits[k] = in ? (uint16_t)t.N[nb + c0 + k] : (uint16_t)0;
+  }
+  if (lane < 44) rec->pad1[lane] = 0;
+  if (lane == 0) {
+    rec->turn = root->turn; rec->pad0 = 0;
+    rec->n = (uint16_t)(nc < FPC_TUPLE_MAXC ? nc : FPC_TUPLE_MAXC);
+    rec->z = 0.f; rec->game = game_id ? game_id[g] : g; rec->ply = ply;
+  }
+}
+
+// z by (game, team of the side to move): alphazero.py:128-137 / :161-175
+__global__ void __launch_bounds__(256) k_tuples_set_z(fpc_tuple *recs, int count, const int *game_id, const float *z0, const float *z1, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const int game = recs[i].game;
+  for (int k = 0; k < n; ++k)
+    if (game_id[k] == game) { recs[i].z = (recs[i].turn & 1) ? z1[k] : z0[k]; return; }
+}
+
 // ================================================================================================
 // k_select: get_expandable_leaves / Node::ChooseLeaf (mcts.py:18-26, node.cpp:19-78)
 // ================================================================================================

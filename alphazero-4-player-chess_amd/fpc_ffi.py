@@ -41,6 +41,18 @@ class Stats(C.Structure):
                 ("sims", C.c_uint64), ("nodes", C.c_uint64)]
 
 
+MAX_TUPLE_C = 256
+
+
+class Tuple(C.Structure):
+    """fpc_tuple: one (state, pi, z) training record, 1280 bytes (include/fpc_engine.h)."""
+    _fields_ = [("sq", C.c_uint8 * MAX_SQ), ("turn", C.c_uint8), ("pad0", C.c_uint8), ("n", C.c_uint16), ("z", C.c_float),
+                ("game", C.c_int32), ("ply", C.c_int32), ("flat", C.c_uint16 * MAX_TUPLE_C), ("visits", C.c_uint16 * MAX_TUPLE_C),
+                ("pad1", C.c_uint8 * 44)]
+
+
+assert C.sizeof(Tuple) == 1280
+
 P = C.POINTER
 _SIGS = {
     "fpc_abi_version": (C.c_int, []),
@@ -73,6 +85,17 @@ _SIGS = {
     "fpc_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "fpc_set_policy_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "fpc_stream": (C.c_void_p, [C.c_void_p]),
+    "fpc_tuples_reserve": (C.c_int, [C.c_void_p, C.c_int]),
+    "fpc_tuples_reset": (C.c_int, [C.c_void_p]),
+    "fpc_collect_tuples": (C.c_int, [C.c_void_p, P(C.c_int), C.c_int]),
+    "fpc_tuples_set_z": (C.c_int, [C.c_void_p, P(C.c_int), P(C.c_float), P(C.c_float), C.c_int]),
+    "fpc_tuples_count": (C.c_int, [C.c_void_p]),
+    "fpc_tuples_read": (C.c_int, [C.c_void_p, P(Tuple), C.c_int, C.c_int]),
+    "fpc_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "fpc_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "fpc_comm_destroy": (C.c_int, [C.c_void_p]),
+    "fpc_allgather_tuples": (C.c_int, [C.c_void_p, P(C.c_int), P(C.c_int)]),
+    "fpc_gathered_read": (C.c_int, [C.c_void_p, P(Tuple), C.c_int, C.c_int]),
 }
 EXPORTS = sorted(_SIGS)
 
@@ -105,6 +128,16 @@ def lib():
             pass
         _lib = bind(C.CDLL(LIB_PATH))
     return _lib
+
+
+def comm_unique_id(_lib=None):
+    """rank 0: the 128-byte ncclUniqueId to hand to the other ranks"""
+    L = _lib if _lib is not None else lib()
+    buf = (C.c_char * 128)()
+    rc = L.fpc_comm_unique_id(buf)
+    if rc != 0:
+        raise RuntimeError("fpc_comm_unique_id failed (%d): %s" % (rc, (L.fpc_last_error(None) or b"").decode()))
+    return bytes(buf)
 
 
 def clone_board(b):
@@ -259,6 +292,46 @@ class Engine:
 
     def set_timing(self, on):
         self.L.fpc_set_timing(self.h, 1 if on else 0)
+
+    # ---- training tuples (device resident) and their RCCL exchange ----
+    def tuples_reserve(self, capacity):
+        self._chk(self.L.fpc_tuples_reserve(self.h, int(capacity)))
+
+    def tuples_reset(self):
+        self._chk(self.L.fpc_tuples_reset(self.h))
+
+    def collect_tuples(self, game_ids, ply):
+        """one tuple per game of the search that just finished (root mailbox, side to move, sparse pi)"""
+        ids = (C.c_int * len(game_ids))(*game_ids) if game_ids is not None else None
+        self._chk(self.L.fpc_collect_tuples(self.h, ids, int(ply)))
+
+    def tuples_set_z(self, game_ids, z_team0, z_team1):
+        n = len(game_ids)
+        self._chk(self.L.fpc_tuples_set_z(self.h, (C.c_int * n)(*game_ids), (C.c_float * n)(*z_team0), (C.c_float * n)(*z_team1), n))
+
+    def tuples_count(self):
+        return self.L.fpc_tuples_count(self.h)
+
+    def tuples_read(self, first=0, n=None):
+        n = self.tuples_count() - first if n is None else n
+        arr = (Tuple * max(n, 1))()
+        self._chk(self.L.fpc_tuples_read(self.h, arr, first, n))
+        return arr, n
+
+    def comm_init(self, id128, rank, world):
+        buf = (C.c_char * 128).from_buffer_copy(bytes(id128))
+        self._chk(self.L.fpc_comm_init(self.h, buf, rank, world))
+
+    def allgather_tuples(self):
+        """episode end: RCCL all-gather of every rank's tuples, driven from the C++ host.
+        Returns (per-rank counts, ctypes array of all tuples in rank order)."""
+        w = C.c_int * 64
+        counts, total = w(), C.c_int()
+        self._chk(self.L.fpc_allgather_tuples(self.h, counts, C.byref(total)))
+        arr = (Tuple * max(total.value, 1))()
+        if total.value:
+            self._chk(self.L.fpc_gathered_read(self.h, arr, 0, total.value))
+        return counts, arr, total.value
 
 
 def board_from_dict(R, turn, entries, castle=None, _lib=None):

@@ -9,11 +9,14 @@ rank all-gathers its compact records once per episode over RCCL (backend "nccl" 
 Dense reference-shaped tensors (encoded state [24,R,R] via the engine, pi [A] = visits/sum) are
 rebuilt on receipt (`dense_pi`).  Variable length => all-gather of byte counts, then one padded
 all-gather of the payload (latency-bound: a single fused collective per episode)."""
+import ctypes as C
 import struct
 
 import numpy as np
 import torch
 import torch.distributed as dist
+
+import fpc_ffi
 
 
 def shard_games(n_games, rank, world):
@@ -62,3 +65,67 @@ def all_gather_bytes(payload, device="cpu", group=None):
     bufs = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(bufs, mine, group=group)
     return [bytes(b[:s].cpu().numpy().tobytes()) for b, s in zip(bufs, sizes)]
+
+
+# ---- native tuples (fpc_tuple PODs built on the device by fpc_collect_tuples) -------------------
+def records_of(arr, n, R):
+    """ctypes fpc_tuple array -> list of record dicts (same keys as unpack_records + game, ply)"""
+    out = []
+    for i in range(n):
+        t = arr[i]
+        k = int(t.n)
+        out.append({"mailbox": np.frombuffer(bytes(t.sq), np.uint8, R * R).copy(), "turn": int(t.turn), "z": float(t.z),
+                    "flat": np.asarray(t.flat[:k], np.int64), "visits": np.asarray(t.visits[:k], np.int64),
+                    "game": int(t.game), "ply": int(t.ply)})
+    return out
+
+
+def exchange(eng, group=None):
+    """Episode-end all-gather of the tuples collected on this rank's engine.  Returns the
+    records of ALL ranks, rank-major.  With an RCCL communicator on the engine (fpc_comm_init; bench.py
+    --gpus N) the collective is issued by the C++ host on device memory; otherwise (gloo, CPU tests)
+    the same PODs travel through torch.distributed as bytes."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        arr, n = eng.tuples_read()
+        return records_of(arr, n, eng.R)
+    if getattr(eng, "has_comm", False):
+        _counts, arr, total = eng.allgather_tuples()
+        return records_of(arr, total, eng.R)
+    arr, n = eng.tuples_read()
+    payload = bytes(memoryview(arr).cast("B")[:n * C.sizeof(fpc_ffi.Tuple)]) if n else b""
+    out = []
+    for blob in all_gather_bytes(payload, group=group):
+        m = len(blob) // C.sizeof(fpc_ffi.Tuple)
+        if m:
+            out += records_of((fpc_ffi.Tuple * m).from_buffer_copy(blob), m, eng.R)
+    return out
+
+
+def init_comm(eng, device=None, group=None):
+    """RCCL communicator for `eng`, the 128-byte id travelling over the existing torch.distributed group"""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = device if device is not None else "cpu"
+    idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        idt = torch.frombuffer(bytearray(fpc_ffi.comm_unique_id(eng.L)), dtype=torch.uint8).to(dev)
+    dist.broadcast(idt, 0, group=group)
+    eng.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+    eng.has_comm = True
+
+
+def dense_batch(eng, recs):
+    """(encoded state [n,24,R,R] f32, pi [n,A] f32, z [n,1] f32) as the reference's trainer stacks them
+    (alphazero.py:186-197): GetEncodedState per tuple (own rotation), pi = N / sum N"""
+    boards = []
+    for r in recs:
+        b = fpc_ffi.Board()
+        for i, v in enumerate(r["mailbox"]):
+            b.sq[i] = int(v)
+        b.turn = r["turn"]
+        for c in range(4):
+            b.king[c] = fpc_ffi.NO_SQ
+        boards.append(b)
+    enc = np.concatenate([eng.encode([b]) for b in boards]) if boards else np.zeros((0, 24, eng.R, eng.R), np.float32)
+    pi = torch.stack([dense_pi(r, eng.A) for r in recs]) if recs else torch.zeros(0, eng.A)
+    z = torch.tensor([r["z"] for r in recs], dtype=torch.float32).view(-1, 1)
+    return torch.from_numpy(enc), pi, z

@@ -8,10 +8,15 @@ One "step" = one MCTS.search call over the whole batch of concurrent games (one 
 by the move selection + TakeAction + GetGameResult that the reference's play() loop performs
 (alphazero.py:99-144), so that successive steps see realistic positions.  Workload at every N:
 BASELINE.json configs[1] per GPU -- 256 concurrent games x 400 sims/move, 10-block/128-filter
-ResNet, 14x14 STANDARD start, bf16 MFMA operands, random-init weights (torch.manual_seed(0)),
-synthetic data.  N > 1: one process per GPU (torchrun), games sharded 256/GPU (weak scaling), no
-data-path collective inside the search; the (state, pi, z)-tuple all-gather over RCCL that ends an
-episode is executed once inside the timed region.
+ResNet, 14x14 STANDARD start, random-init weights (torch.manual_seed(0)), synthetic data.
+MFMA operand type: fp16 by default -- it is the 16-bit type that meets north_star's float bar (logits
+within 1e-3 of the reference's fp32 net.py: 3.1e-4, tests/test_net_gpu.py) at the same MFMA rate;
+configs[1]'s bf16 does not (2.3e-3) and is measured right after the timed region and reported beside
+the headline as `alt_dtype_bf16` with both measured errors in `float_parity`.
+N > 1: one process per GPU (torchrun), games sharded 256/GPU (weak scaling), no data-path collective
+inside the search; training tuples are built on the device (fpc_collect_tuples) and the all-gather
+that ends an episode is one ncclAllGather issued by the engine's C++ host over RCCL/xGMI
+(fpc_allgather_tuples), executed once inside the timed region.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel group (the MFMA
 implicit-GEMM network forward) with HIP events recorded on the engine's own stream during the
@@ -93,7 +98,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=10)
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--board", type=int, default=14)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"])
+    ap.add_argument("--no-alt-dtype", action="store_true", help="skip the extra measurement with the other 16-bit operand type")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true", help="developer knob: no HIP events between the stages (what do they cost?)")
     ap.add_argument("--no-alt-policy-head", action="store_true", help="skip the extra legal-only-policy-head measurement")
@@ -136,7 +142,11 @@ def main():
     start = fpc_ffi.board_from_dict(R, turn, entries)
     boards = [fpc_ffi.clone_board(start) for _ in range(G)]
     rng = np.random.default_rng(1234 + rank)
-    tuples = []          # compact (mailbox+turn, sparse pi) records of this rank's episode
+    # episode bookkeeping: every concurrent game carries a job-wide unique id; tuples are built on the
+    # device by fpc_collect_tuples, z is assigned when a game ends (alphazero.py:128-137, quirk Q12) or,
+    # for games still running at the end, by the material heuristic (alphazero.py:161-175)
+    state = {"ids": [g * world + rank for g in range(G)], "next": G, "ply": [0] * G, "step": 0}
+    eng.tuples_reserve(G * (args.steps + 1))
 
     def step(record):
         nonlocal boards
@@ -144,19 +154,29 @@ def main():
         eng.search_run(sims)
         res = eng.search_results(roots=boards)
         flats = pick_moves(res, rng, 1.1)
-        if record:      # (state, pi) of this ply; z is assigned at episode end (alphazero.py:112,128-137)
-            for g in range(G):
-                n = int(res["n_children"][g])
-                tuples.append(tuples_mod.pack_record(R, bytes(boards[g])[:R * R], boards[g].turn, 0.0,
-                                                     res["flat"][g, :n], res["visits"][g, :n]))
+        if record:      # (state, pi) of this ply for every game, on the device
+            eng.collect_tuples(state["ids"], state["step"])
+        state["step"] += 1
         ok = [g for g in range(G) if flats[g] >= 0]
         nxt = eng.take_action([boards[g] for g in ok], [int(flats[g]) for g in ok])
         results = eng.game_result(nxt)
+        done_ids, z0, z1 = [], [], []
         for g, nb, r in zip(ok, nxt, results):
-            boards[g] = nb if r == 0 else fpc_ffi.clone_board(start)     # finished game -> new episode
+            state["ply"][g] += 1
+            if r == 0:
+                boards[g] = nb
+                continue
+            losing_team = boards[g].turn & 1               # the team that just moved (Q12)
+            done_ids.append(state["ids"][g]); z0.append(1.0 if losing_team != 0 else -1.0); z1.append(1.0 if losing_team != 1 else -1.0)
+            boards[g] = fpc_ffi.clone_board(start)         # finished game -> new episode, new id
+            state["ids"][g] = state["next"] * world + rank
+            state["next"] += 1
+            state["ply"][g] = 0
         for g in range(G):
             if flats[g] < 0:
                 boards[g] = fpc_ffi.clone_board(start)
+        if record and done_ids:
+            eng.tuples_set_z(done_ids, z0, z1)
         return int(res["sims_done"].sum())
 
     def sync():
@@ -166,12 +186,20 @@ def main():
             torch.cuda.synchronize()
 
     def gather_tuples():
-        """episode end: all-gather of this rank's (state, pi) records over RCCL/xGMI."""
-        if world == 1 or not tuples:
-            return 0
-        got = tuples_mod.all_gather_bytes(b"".join(tuples), device=torch.device("cuda", local))
-        torch.cuda.synchronize()
-        return sum(len(x) for x in got)
+        """episode end: z of the games still running (heuristic), then the all-gather of this rank's
+        tuples over RCCL/xGMI, issued by the engine's C++ host."""
+        ids, z0, z1 = [], [], []
+        for g in range(G):
+            h = eng.L.fpc_board_heuristic(boards[g], boards[g].turn & 1) * 0.02
+            ids.append(state["ids"][g]); z0.append(h if (boards[g].turn & 1) == 0 else -h); z1.append(h if (boards[g].turn & 1) == 1 else -h)
+        eng.tuples_set_z(ids, z0, z1)
+        if world == 1:
+            return eng.tuples_count() * 1280
+        recs = tuples_mod.exchange(eng)
+        return len(recs) * 1280
+
+    if world > 1 and args.backend == "nccl":
+        tuples_mod.init_comm(eng, device=torch.device("cuda", local))
 
     for _ in range(args.warmup):
         step(False)
@@ -220,8 +248,41 @@ def main():
             atotal = int(as_.item())
         alt = {"value": atotal / aelapsed, "unit": "sims/s", "steps": 3,
                "note": "NOT the headline: policy Linear evaluated only at the leaves' legal moves (softmax denominator "
-                       "cancels in mask+renormalise); priors equal the full head's up to f32 rounding, visit counts identical in "
-                       "tests/test_nn_gpu.py::test_legal_only_policy_head_matches_full; opt-in via fpc_set_policy_mode"}
+                       "cancels in mask+renormalise); priors equal the full head's within 2e-5 (f32 rounding), so a PUCT near-tie can "
+                       "resolve differently: tests/test_nn_gpu.py::test_legal_only_policy_head_matches_full reports how many games "
+                       "searched differently (none in the recorded runs); opt-in via fpc_set_policy_mode"}
+
+    # Reported beside the headline, never as `value`: the same job with the OTHER 16-bit MFMA operand
+    # type (BASELINE configs[1] names bf16; the headline is fp16 because only fp16 meets the 1e-3 logits bar)
+    alt_dtype = None
+    other = "bf16" if args.dtype == "fp16" else "fp16"
+    if not args.no_alt_dtype:
+        eng.close()
+        odt = 0 if other == "bf16" else 1
+        eng = fpc_ffi.Engine(R, INV, max_games=G, max_sims=sims, device=local, nn_dtype=odt)
+        eng.set_policy_mode(args.policy_head == "legal")
+        eng.load_weights(weights.export_weights(model, odt))
+        eng.tuples_reserve(G)
+        boards = [fpc_ffi.clone_board(start) for _ in range(G)]
+        state.update({"ids": [g * world + rank for g in range(G)], "next": G, "ply": [0] * G, "step": 0})
+        step(False)
+        sync()
+        b0 = time.perf_counter()
+        btotal = 0
+        for _ in range(4):
+            btotal += step(False)
+        sync()
+        belapsed = time.perf_counter() - b0
+        if world > 1:
+            bt = torch.tensor([belapsed], device="cuda", dtype=torch.float64)
+            dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+            belapsed = float(bt.item())
+            bs = torch.tensor([float(btotal)], device="cuda", dtype=torch.float64)
+            dist.all_reduce(bs, op=dist.ReduceOp.SUM)
+            btotal = int(bs.item())
+        alt_dtype = {"dtype": other, "value": btotal / belapsed, "unit": "sims/s", "steps": 4,
+                     "note": "same workload, other 16-bit MFMA operand type; see float_parity for which type meets the 1e-3 logits bar"}
+    eng.close()
 
     if rank != 0:
         if world > 1:
@@ -239,6 +300,8 @@ def main():
     peak = PEAK_TFLOPS[args.dtype]
     ach_tower = flops_tower / (tower_ms * 1e-3) / 1e12 if tower_ms > 0 else 0.0
     ach_fc = flops_fc / (fc_ms * 1e-3) / 1e12 if fc_ms > 0 else 0.0
+    Np, Kp = (A + 255) // 256 * 256, (A + 511) // 512 * 512
+    fc_bytes = 2.0 * Np * Kp + 2.0 * G * Kp + 4.0 * G * A
     pmc = {}
     try:     # HBM bytes per launch measured with rocprofv3 --pmc (tools/pmc_nn.sh), committed under profiles/
         pmc = json.load(open(os.path.join(HERE, "profiles", "pmc_summary.json")))
@@ -259,11 +322,14 @@ def main():
                      "traffic": pmc.get("k_tower", {}).get("hbm_bytes"),
                      "kernel": "k_tower (residual tower megakernel, LDS-resident activations)",
                      "flops_per_launch": flops_tower, "ms_per_launch": tower_ms},
-        "roofline_policy_linear": {"bound": "mfma", "achieved": ach_fc, "peak": peak, "unit": "TFLOP/s", "frac": ach_fc / peak,
-                                   "traffic": pmc.get("k_fc256", {}).get("hbm_bytes"),
-                                   "kernel": "k_fc256 + k_fc_reduce (weight-streaming Linear, 1.1 GB of bf16 weights per launch)",
-                                   "flops_per_launch": flops_fc, "ms_per_launch": fc_ms,
-                                   "weight_stream_GBps": (2.0 * ((A + 127) // 128 * 128) * ((A + 511) // 512 * 512)) / (fc_ms * 1e-3) / 1e9 if fc_ms > 0 else 0.0},
+        # the policy Linear at M = 256: 255 FLOP per weight byte, below the 312 FLOP/B ridge -> HBM-bound.
+        # algorithmic bytes = the 16-bit weight matrix read once + X read once + f32 logits written once
+        "roofline_policy_linear": {"bound": "hbm", "achieved": fc_bytes / (fc_ms * 1e-3) / 1e9 if fc_ms > 0 else 0.0, "peak": PEAK_HBM_GBS,
+                                   "unit": "GB/s", "frac": (fc_bytes / (fc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if fc_ms > 0 else 0.0,
+                                   "traffic": (pmc.get("k_fc", {}).get("hbm_bytes", 0) + pmc.get("k_fc_reduce", {}).get("hbm_bytes", 0)) or None,
+                                   "kernel": "k_fc + k_fc_reduce (weight-streaming Linear, 1.1 GB of 16-bit weights per launch)",
+                                   "bytes_per_launch": fc_bytes, "flops_per_launch": flops_fc, "ms_per_launch": fc_ms,
+                                   "mfma_TFLOPs": ach_fc},
         "stage_ms_per_sim_step": {"select+encode": sel_ms, "tower": tower_ms, "policy_linear": fc_ms, "expand+backup": exp_ms},
         "tree_hbm": {"bound": "hbm", "algorithmic_bytes_per_sim": tree_bytes_per_sim(R),
                      "achieved": tree_bytes_per_sim(R) * G / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0,
@@ -271,14 +337,51 @@ def main():
                      "frac": (tree_bytes_per_sim(R) * G / (tree_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if tree_ms > 0 else 0.0,
                      "kernels": "k_select + k_expand (+ the leaf encode, done inside k_tower) -- latency-bound: one wavefront per game"},
     }
-    if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
+    if not args.no_cpu_baseline and world == 1:      # reported baselines: rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(R, INV, model, args)
+        out["cpu_baseline_config0"] = cpu_baseline_config0()
     if alt is not None:
         out["alt_policy_head_legal_only"] = alt
+    if alt_dtype is not None:
+        out["alt_dtype_" + other] = alt_dtype
+    if world == 1 and not args.no_alt_dtype:
+        out["float_parity"] = float_parity(R, args.blocks, args.hidden, INV)
     out["config"]["policy_head"] = args.policy_head
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def float_parity(R, blocks, hidden, INV):
+    """max|dlogit| / max|dvalue| of the engine's network against the fp32 logits recorded from the
+    reference's own net.py (tests/golden/net_r*_b*_h*.npz, oracle/gen_net_golden.py), both operand
+    types -- the measurement behind the choice of the headline dtype (north_star: within 1e-3)."""
+    import torch
+    import fpc_ffi
+    import weights
+    try:
+        import net_cases as nc
+        fx = nc.load_net_fixture(R, blocks, hidden)
+    except Exception as exc:
+        return {"error": "no reference-net fixture for this shape: %r" % (exc,)}
+    model = nc.fixture_model(fx)
+    boards = nc.fixture_boards(fx)
+    n = len(boards)
+    out = {"tolerance": 1e-3, "fixture": "tests/golden/net_r%d_b%d_h%d.npz (reference net.py, fp32 CPU, %d golden positions)" % (R, blocks, hidden, n)}
+    for name, dt in (("fp16", 1), ("bf16", 0)):
+        eng = fpc_ffi.Engine(R, INV, max_games=n, max_sims=4, nn_dtype=dt)
+        eng.load_weights(weights.export_weights(model, dt))
+        enc = np.concatenate([eng.encode([b]) for b in boards])
+        x = torch.from_numpy(enc).cuda()
+        lg = torch.empty(n, eng.A, device="cuda")
+        va = torch.empty(n, device="cuda")
+        torch.cuda.synchronize()
+        eng.nn_forward(x.data_ptr(), n, lg.data_ptr(), va.data_ptr())
+        el = float(np.abs(lg.cpu().numpy()[:, fx["idx"]] - fx["logits"]).max())
+        ev = float(np.abs(va.cpu().numpy() - fx["value"]).max())
+        out[name] = {"max_abs_dlogit": el, "max_abs_dvalue": ev, "meets_tolerance": bool(el < 1e-3 and ev < 1e-3)}
+        eng.close()
+    return out
 
 
 def baseline_metric():
@@ -324,6 +427,41 @@ def cpu_baseline(R, INV, model, args):
     return {"value": done / dt, "unit": "sims/s", "cores": cores, "kind": "port",
             "sample": "%d games x %d sims from the start position, oracle tree + PyTorch-CPU fp32 ResNet(%d,%d), %.1f s"
                       % (Gc, sc, args.blocks, args.hidden, dt)}
+
+
+def cpu_baseline_config0():
+    """BASELINE configs[0]: 1 self-play game, 100 sims/move, 4-block/64-filter ResNet on PyTorch-CPU at
+    the reference's compiled board size (8x8/2, EIGHT_SIMPLE): the oracle's MCTS.search + fp32 ResNet."""
+    import torch
+    import net
+    import positions
+    from oracle import orc
+    R, INV = 8, 2
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = net.ResNet(Spec(R), 4, 64, "cpu").eval()
+    turn, entries = positions.start_entries(R)
+
+    def ev(enc):
+        with torch.no_grad():
+            lg, v = model(torch.from_numpy(np.ascontiguousarray(enc)))
+        return lg.numpy(), v.squeeze(1).numpy()
+
+    done, t0 = 0, time.perf_counter()
+    b = orc.board_from_dict(R, turn, [list(e) for e in entries])
+    for _ply in range(6):                      # six plies of one game, 100 simulations each
+        rc, res = orc.search([b], R, INV, 100, 3.0, ev)
+        done += res[0]["sims_done"]
+        if not res[0]["children"]:
+            break
+        best = max(res[0]["children"], key=lambda c: c[1])[0]
+        b, _ = orc.take_action(res[0]["board"], R, best)
+        if orc.game_result(orc.clone(b), R, INV) != 0:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "sims/s", "cores": cores, "kind": "port",
+            "sample": "configs[0]: 1 game x 100 sims/move x 6 plies, 8x8 EIGHT_SIMPLE, oracle tree + PyTorch-CPU fp32 ResNet(4,64), %.1f s" % dt}
 
 
 if __name__ == "__main__":

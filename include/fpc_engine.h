@@ -40,7 +40,8 @@ typedef enum fpc_status {
   FPC_EMOVE = -7,       /* engine/board.cpp:1046-1054 "piece missing for move" */
   FPC_EUNSUPPORTED = -8,/* reserved */
   FPC_ESTATE = -9,      /* call sequence error */
-  FPC_EWEIGHTS = -10    /* weight blob malformed / not loaded */
+  FPC_EWEIGHTS = -10,   /* weight blob malformed / not loaded */
+  FPC_ECOMM = -11       /* RCCL failure (library missing, communicator error): message names the ncclResult */
 } fpc_status;
 
 /* chess::GameResult, engine/board.h:438-444 */
@@ -161,6 +162,47 @@ int fpc_search_grandchildren(fpc_engine *e, int game, int child_idx, int max_chi
 int fpc_load_weights(fpc_engine *e, const void *blob, uint64_t nbytes);
 /* forward only: enc_dev [n,24,R,R] f32 -> logits_dev [n,A] f32, value_dev [n] f32 (DEVICE pointers) */
 int fpc_nn_forward(fpc_engine *e, const float *enc_dev, int n, float *logits_dev, float *value_dev);
+
+/* ---- training tuples and their episode-end exchange ---------------------------------------
+ * The reference keeps (state, pi, z) tuples as Python objects: Board::AppendToMemory(MemoryEntry(state,
+ * action_probs)) per ply (alphazero.py:104-112), rewards assigned when the game ends
+ * (handle_terminal_state, alphazero.py:53-78; heuristic scoring at max_game_length, :161-175).  Here a
+ * tuple is a fixed-size POD built ON THE DEVICE from the finished search (root mailbox + side to move +
+ * sparse pi = the root's (child flat index, visit count) pairs) and kept in a device buffer until the
+ * episode ends.  Dense reference-shaped tensors (GetEncodedState [24,R,R], pi [A] = N / sum N) are
+ * rebuilt from it on receipt (alphazero-4-player-chess_amd/tuples.py). */
+#define FPC_TUPLE_MAXC 256
+typedef struct fpc_tuple {
+  uint8_t sq[FPC_MAX_SQ];        /* root mailbox (piece bytes as in fpc_board) */
+  uint8_t turn;                  /* side to move at the root */
+  uint8_t pad0;
+  uint16_t n;                    /* number of (flat, visits) pairs */
+  float z;                       /* filled by fpc_tuples_set_z */
+  int32_t game, ply;             /* caller's game id and ply */
+  uint16_t flat[FPC_TUPLE_MAXC];
+  uint16_t visits[FPC_TUPLE_MAXC];
+  uint8_t pad1[44];
+} fpc_tuple;                     /* sizeof == 1280 */
+int fpc_tuples_reserve(fpc_engine *e, int capacity);    /* device buffer for `capacity` tuples; drops collected ones */
+int fpc_tuples_reset(fpc_engine *e);                    /* new episode: count = 0 */
+/* after a finished search (fpc_search_run / the select-expand loop): one tuple per game of that search,
+ * appended in game order.  game_id: host array [n_games] (NULL: 0..n_games-1). */
+int fpc_collect_tuples(fpc_engine *e, const int *game_id, int ply);
+/* z of every collected tuple whose game is game_id[i]: z_team[i][side-to-move team of the tuple]
+ * (alphazero.py:128-137: +1 / -1 by team, quirk Q12; :161-175: +-heuristic) */
+int fpc_tuples_set_z(fpc_engine *e, const int *game_id, const float *z_team0, const float *z_team1, int n);
+int fpc_tuples_count(fpc_engine *e);
+int fpc_tuples_read(fpc_engine *e, fpc_tuple *host_out, int first, int n);
+/* RCCL, driven from the C++ host (one communicator per engine = per GPU; no torch involved):
+ * rank 0 makes the 128-byte id and hands it to the other ranks by whatever channel the caller has. */
+int fpc_comm_unique_id(void *id128);
+int fpc_comm_init(fpc_engine *e, const void *id128, int rank, int world);
+int fpc_comm_destroy(fpc_engine *e);
+/* episode end: one ncclAllGather of the per-rank counts and one of the max-padded tuple
+ * arrays over xGMI.  counts_out: host [world].  The gathered tuples stay on the device, rank-major
+ * (rank r's tuples first .. counts_out[r] of them), and are read with fpc_gathered_read. */
+int fpc_allgather_tuples(fpc_engine *e, int *counts_out, int *total_out);
+int fpc_gathered_read(fpc_engine *e, fpc_tuple *host_out, int first, int n);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------- */
 typedef struct fpc_stats {

@@ -22,11 +22,12 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(fpc_ffi.EXPORTS)
-    assert lib.fpc_abi_version() == 3
+    assert lib.fpc_abi_version() == 4
 
 
 def test_pod_layouts():
-    assert C.sizeof(fpc_ffi.Board) == 288 and C.sizeof(fpc_ffi.Move) == 8
+    assert C.sizeof(fpc_ffi.Board) == 288 and C.sizeof(fpc_ffi.Move) == 8 and C.sizeof(fpc_ffi.Tuple) == 1280
+    assert fpc_ffi.Tuple.n.offset == 198 and fpc_ffi.Tuple.z.offset == 200 and fpc_ffi.Tuple.flat.offset == 212 and fpc_ffi.Tuple.visits.offset == 724
     assert fpc_ffi.Board.pl.offset == 196 and fpc_ffi.Board.turn.offset == 196 + 64 + 12
 
 

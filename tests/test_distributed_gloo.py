@@ -80,3 +80,89 @@ def test_record_roundtrip():
     out = tuples.unpack_records(R, rec + rec)
     assert len(out) == 2 and out[1]["turn"] == 3 and out[1]["z"] == -1.0
     assert out[0]["flat"].tolist() == [5, 77, 4000] and out[0]["visits"].tolist() == [9, 8, 300]
+
+
+# ---- the same exchange on REAL engine output -----------------------------------------------------
+def _shard_episode(eng, backend, R, game_ids, plies, sims):
+    """a few plies of self-play on the engine for the games `game_ids` (one batch, reference order);
+    tuples are collected natively (fpc_collect_tuples) and z assigned at the end (fpc_tuples_set_z)"""
+    import evaluators
+    import fpc_ffi
+    import positions
+    import selfplay
+    from fpc_testlib import run_external_search
+    turn, entries = positions.start_entries(R)
+    boards = [fpc_ffi.board_from_dict(R, turn, entries, _lib=eng.L) for _ in game_ids]
+    ev = evaluators.make("hash", R)
+    eng.tuples_reserve(len(game_ids) * plies)
+    for ply in range(plies):
+        res = run_external_search(eng, backend, boards, sims, 3.0, ev)
+        eng.collect_tuples(game_ids, ply)
+        picks = []
+        for i, g in enumerate(game_ids):
+            n = int(res["n_children"][i])
+            picks.append(selfplay.sample_action(res["flat"][i, :n], res["visits"][i, :n], 1.1, ((g * 7 + ply * 3) % 10) / 10.0))
+        boards = eng.take_action(boards, picks)
+    # reward rule of the reference's max-length scoring (alphazero.py:161-175): +-heuristic by team
+    z0, z1 = [], []
+    for b in boards:
+        h = eng.L.fpc_board_heuristic(b, b.turn & 1) * 0.02
+        z0.append(h if (b.turn & 1) == 0 else -h)
+        z1.append(h if (b.turn & 1) == 1 else -h)
+    eng.tuples_set_z(game_ids, z0, z1)
+
+
+def _engine_worker(rank, world, port, n_games, R, plies, sims, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fpc_testlib import make_engine
+    mine = tuples.shard_games(n_games, rank, world)
+    eng = make_engine("emul", R, 2, max_games=len(mine), max_sims=sims)
+    _shard_episode(eng, "emul", R, mine, plies, sims)
+    recs = tuples.exchange(eng)                      # gloo transport of the native PODs
+    enc, pi, z = tuples.dense_batch(eng, recs)
+    key = sorted(range(len(recs)), key=lambda i: (recs[i]["game"], recs[i]["ply"]))
+    q.put((rank, [(recs[i]["game"], recs[i]["ply"], recs[i]["turn"], recs[i]["mailbox"].tobytes(), recs[i]["flat"].tolist(),
+                   recs[i]["visits"].tolist(), recs[i]["z"]) for i in key],
+           enc[key].numpy().tobytes(), pi[key].numpy().tobytes(), z[key].numpy().tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+def test_world_size_2_exchange_of_real_engine_tuples():
+    """games sharded g -> rank g mod N, every rank searches its shard on its own engine (the
+    wavefront-emulator build of the product's kernels here), tuples are built by fpc_collect_tuples and
+    all-gathered at episode end; the dense (state, pi, z) reconstructed on EVERY rank must equal what
+    one process gets when it runs the same shards itself."""
+    from fpc_testlib import make_engine
+    R, n_games, plies, sims, world = 8, 4, 3, 12, 2
+    # single-process reference: the same shards (same batch composition, quirk Q6), one engine
+    ref = []
+    for r in range(world):
+        mine = tuples.shard_games(n_games, r, world)
+        eng = make_engine("emul", R, 2, max_games=len(mine), max_sims=sims)
+        _shard_episode(eng, "emul", R, mine, plies, sims)
+        arr, n = eng.tuples_read()
+        ref += tuples.records_of(arr, n, R)
+        eng_last = eng
+    assert len(ref) == n_games * plies
+    enc, pi, z = tuples.dense_batch(eng_last, ref)
+    key = sorted(range(len(ref)), key=lambda i: (ref[i]["game"], ref[i]["ply"]))
+    want = ([(ref[i]["game"], ref[i]["ply"], ref[i]["turn"], ref[i]["mailbox"].tobytes(), ref[i]["flat"].tolist(),
+              ref[i]["visits"].tolist(), ref[i]["z"]) for i in key],
+            enc[key].numpy().tobytes(), pi[key].numpy().tobytes(), z[key].numpy().tobytes())
+    assert abs(float(pi.sum(dim=1).min()) - 1.0) < 1e-6 and any(t[6] != 0.0 for t in want[0])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_engine_worker, args=(r, world, port, n_games, R, plies, sims, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, recs, e, p_, z_ in got:
+        assert recs == want[0], rank
+        assert e == want[1] and p_ == want[2] and z_ == want[3], rank

@@ -64,6 +64,7 @@ struct fpc_engine {
   int tuple_cap = 0, tuple_count = 0;
   int *d_tgame = nullptr;           // [max_games] game ids of one collect / set_z call
   float *d_tz = nullptr;            // [2][max_games]
+  float *d_noise = nullptr;         // [max_games][FPC_MAX_MOVES] root-noise gamma draws (N4)
   void *comm = nullptr;             // ncclComm_t
   int comm_rank = 0, comm_world = 1;
   fpc_tuple *d_gather = nullptr;    // [world][gather_stride]
@@ -244,11 +245,11 @@ int fpc_move_flat_index(int R, int from, int to) {
   const bool queen = dx == 0 || dy == 0 || ax == ay;
   const bool knight = (ax == 1 && ay == 2) || (ax == 2 && ay == 1);
   if (!queen && !knight) return -1;
-  DevCfg c{R, 0, R * R, 8 * R + 8, (8 * R + 8) * R * R};
+  DevCfg c{R, 0, R * R, 8 * R + 8, (8 * R + 8) * R * R, 0};
   return move_plane(c, from, to) * R * R + from;
 }
 int fpc_flat_to_move(int R, int flat, int *from, int *to) {
-  DevCfg c{R, 0, R * R, 8 * R + 8, (8 * R + 8) * R * R};
+  DevCfg c{R, 0, R * R, 8 * R + 8, (8 * R + 8) * R * R, 0};
   if (flat < 0 || flat >= c.A) return FPC_EINVAL;
   *to = flat_to(c, flat, from);
   return 0;
@@ -317,7 +318,7 @@ int fpc_create(const fpc_config *cfg, fpc_engine **out) {
   fpc_engine *e = new fpc_engine();
   e->cfg = *cfg;
   if (e->cfg.avg_children <= 0) e->cfg.avg_children = 96;
-  e->dc = DevCfg{R, INV, R * R, 8 * R + 8, (8 * R + 8) * R * R};
+  e->dc = DevCfg{R, INV, R * R, 8 * R + 8, (8 * R + 8) * R * R, FPC_RULES_STRICT};
   int r = 0;
   auto bail = [&](int code) { g_create_error = e->err; fpc_destroy(e); return code; };
   if (hipStreamCreate(&e->stream) != hipSuccess) { e->err = "hipStreamCreate failed"; return bail(FPC_ENODEVICE); }
@@ -856,6 +857,30 @@ int fpc_stats_reset(fpc_engine *e) {
 int fpc_set_policy_mode(fpc_engine *e, int mode) {
   if (!e || (mode != FPC_POLICY_FULL && mode != FPC_POLICY_LEGAL)) return fail(e, FPC_EINVAL, "bad policy mode");
   e->policy_mode = mode;
+  return 0;
+}
+
+int fpc_set_rules(fpc_engine *e, int rules) {
+  if (!e || rules < 0 || rules > FPC_RULES_FIXED) return fail(e, FPC_EINVAL, "bad rule set");
+  if (e->searching && rules != e->dc.rules) e->searching = false;     // a search in flight was started under the other rules
+  e->dc.rules = rules;
+#ifndef FPC_EMUL
+  e->nn.dc.rules = rules;
+#endif
+  return 0;
+}
+
+int fpc_search_set_root_noise(fpc_engine *e, const float *gamma, int n_games, float eps) {
+  if (!e) return FPC_EINVAL;
+  USE_DEV(e);
+  if (!gamma) { e->t.noise = nullptr; e->t.noise_eps = 0.f; return 0; }
+  if (n_games < 1 || n_games > e->cfg.max_games || !(eps >= 0.f && eps <= 1.f)) return fail(e, FPC_EINVAL, "bad root-noise arguments");
+  int r;
+  if (!e->d_noise && (r = dalloc(e, &e->d_noise, (size_t)e->cfg.max_games * FPC_MAX_MOVES))) return r;
+  HIPCHK(e, hipMemcpyAsync(e->d_noise, gamma, (size_t)n_games * FPC_MAX_MOVES * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->t.noise = e->d_noise;
+  e->t.noise_eps = eps;
   return 0;
 }
 

@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(GEMV_THREADS) k_policy_gemv(DevCfg c, Tree t, 
   const int total = cum[G];
   const int p0 = (int)((long)total * blockIdx.x / gridDim.x), p1 = (int)((long)total * (blockIdx.x + 1) / gridDim.x);
   if (p0 >= p1) return;
-  const int turn0 = first_leaf_turn(t.leaf_node, t.leaf_turn, G);
+  const int turn_batch = first_leaf_turn(t.leaf_node, t.leaf_turn, G);
   // first game of the range: the last g with cum[g] <= p0 among games that own pairs
   int g = 0;
   { int lo = 0, hi = G; while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cum[mid] <= p0) lo = mid; else hi = mid - 1; } g = lo; }
@@ -332,6 +332,7 @@ __global__ void __launch_bounds__(GEMV_THREADS) k_policy_gemv(DevCfg c, Tree t, 
       const int j = pp - cum[g];
       const int fl = legal[j];
       const int plane = fl / c.RR, pos = fl % c.RR;
+      const int turn0 = (c.rules & FPC_RULES_ROTATION) ? t.leaf_turn[g] : turn_batch;
       const int nsrc = plane * c.RR + rot90_src(c.R, -turn0, pos / c.R, pos % c.R);   // ParseActionspace's inverse rotation
       const u32x4_t *wrow = reinterpret_cast<const u32x4_t *>(W2 + (long)nsrc * Kp) + lane;
       const u32x4_t *xrow = reinterpret_cast<const u32x4_t *>(xs) + lane;
@@ -623,7 +624,7 @@ struct NN {
       in_boards = nullptr;
       t.in16 = in16 + (size_t)guard * 32; t.Wstem = stemW; t.bstem = stem.b; t.Wt = towerW; t.bt = towerB;
       t.xfc = xfc; t.vw = vw; t.value = value_out; t.vb = vb;
-      t.L = 2 * nblocks; t.P = P; t.R = dc.R; t.PP = PP; t.NR = PP - P; t.T0 = (P + 1) / 16; t.n_games = n; t.Kp = Kp; t.A_ch = dc.A_ch;
+      t.L = 2 * nblocks; t.P = P; t.R = dc.R; t.PP = PP; t.NR = PP - P; t.T0 = (P + 1) / 16; t.n_games = n; t.Kp = Kp; t.A_ch = dc.A_ch; t.rules = dc.rules;
       // row tiles of 16 grid positions per wave (two waves along M): 8x8 -> 3, 9..11 -> 5, 12..14 -> 7
       const int mt = dc.R <= 8 ? 3 : dc.R <= 11 ? 5 : 7;
       bool &attr = attr_tower[DT];

@@ -109,6 +109,7 @@ struct TowerArgs {
   float *value;                  // [n_games] = tanh(vb + sum relu(vconv) * vw)
   float vb;
   int L, P, R, PP, NR, T0, n_games, Kp, A_ch;
+  int rules;                     // FPC_RULES_* (rotation / plane numbering of the fused encode)
 };
 
 // LDS-DMA: `PIECES` consecutive 1-KiB pieces (64 lanes x 16 B each) global -> LDS with no VGPR
@@ -197,14 +198,14 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
         reinterpret_cast<const uint32_t *>(g.boards + (size_t)game * g.board_stride + slot)[tid];
     __syncthreads();
     // GetEncodedStates: plane = 6*((colour - turn) & 3) + type - 1, -1 wrapping to 23 (Q7); the whole
-    // batch is rotated by the turn of the first live leaf (Q6)
+    // batch is rotated by the turn of the first live leaf (Q6) -- unless the non-strict rules say otherwise
+    if (g.rules & FPC_RULES_ROTATION) rot_k = lboard->turn;
     for (int r = tid; r < g.PP; r += TW_THREADS) {
       const int pi = r / P, pj = r - pi * P;
       if (pi < 1 || pi > g.R || pj < 1 || pj > g.R) continue;
       const uint8_t p = lboard->sq[rot90_src(g.R, rot_k, pi - 1, pj - 1)];
       if (!present(p)) continue;
-      int plane = 6 * ((colour_of(p) - lboard->turn) & 3) + type_of(p) - 1;
-      if (plane < 0) plane += 24;
+      const int plane = piece_plane(p, lboard->turn, g.rules);
       *reinterpret_cast<uint16_t *>(enc + tw_lay(4, r, plane >> 3) + (plane & 7) * 2) = g.one16;
     }
   } else {

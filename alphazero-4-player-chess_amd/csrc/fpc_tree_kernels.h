@@ -24,6 +24,7 @@ enum { PAWN = 0, KNIGHT = 1, BISHOP = 2, ROOK = 3, QUEEN = 4, KING = 5 };
 
 struct DevCfg {
   int R, INV, RR, A_ch, A;
+  int rules;         // FPC_RULES_* bits (include/fpc_engine.h); 0 = strict reference semantics
 };
 
 // error bits accumulated per game / per board (host maps them to fpc_status)
@@ -51,6 +52,9 @@ struct Tree {
   int *path;         // [G][path_cap] root..leaf node ids of this step's descent (k_select -> k_expand's backup)
   int *path_len;
   int path_cap;
+  // root Dirichlet noise (N4; off when null): gamma draws [G][FPC_MAX_MOVES], one per root child in ascending flat order
+  const float *noise;
+  float noise_eps;
 };
 
 // ---- LDS image of one wave --------------------------------------------------------------------
@@ -136,6 +140,14 @@ __host__ __device__ __forceinline__ int flat_to(const DevCfg &c, int flat, int *
   return row * c.R + col;
 }
 
+// input plane of a piece seen from the side to move (board.cpp:322-336): strict = 6*rel + type - 1 with
+// -1 wrapping to 23 (quirk Q7); FPC_RULES_PLANES = 6*rel + type
+__device__ __forceinline__ int piece_plane(uint8_t p, int turn, int rules) {
+  int plane = 6 * ((colour_of(p) - turn) & 3) + type_of(p);
+  if (!(rules & FPC_RULES_PLANES)) { plane -= 1; if (plane < 0) plane += 24; }
+  return plane;
+}
+
 // torch.rot90(x, k, (-2,-1)) index map: out[i][j] = in[src]   (board.cpp:252-255)
 __device__ __forceinline__ int rot90_src(int R, int k, int i, int j) {
   k &= 3;
@@ -175,9 +187,13 @@ __device__ __forceinline__ void list_move_to_end(uint8_t *list, int len, int sq)
 // MakeMove for a tree/self-play move, which carries only (from,to): capture whatever stands on
 // `to`, no promotion, no rook hop, no rights update (engine/board.cpp:1028-1096 with a
 // Move(flat)/Move(plane,from) argument).  Executed by lane 0.  false: "piece missing".
-__device__ __forceinline__ bool make_move_lane0(fpc_board *b, int from, int to) {
+// With FPC_RULES_FULL_MOVES (the non-strict rule set) the move is executed the way the
+// reference's own generator describes it (engine/board.cpp:58-88, :256-302, :313-466): a pawn that
+// reaches its promotion line becomes a queen, a two-square king move hops the rook, king moves clear the
+// mover's castling rights and a rook leaving its home square clears that side's.
+__device__ __forceinline__ bool make_move_lane0(fpc_board *b, int from, int to, const DevCfg &c) {
   if (to == FPC_NO_SQ) return false;
-  const uint8_t piece = b->sq[from];
+  uint8_t piece = b->sq[from];
   const uint8_t cap = b->sq[to];
   if (present(cap)) {  // RemovePiece(to)
     const int cc = colour_of(cap);
@@ -190,6 +206,46 @@ __device__ __forceinline__ bool make_move_lane0(fpc_board *b, int from, int to) 
   }
   if (!present(piece)) return false;
   const int pc = colour_of(piece);
+  int rook_from = FPC_NO_SQ, rook_to = FPC_NO_SQ;
+  if (c.rules & FPC_RULES_FULL_MOVES) {
+    const int R = c.R, fr = from / R, fc = from % R, tr = to / R, tc = to % R;
+    const int ty = type_of(piece);
+    if (ty == PAWN) {
+      bool promo;
+      switch (pc) {
+        case 0: promo = tr == R / 4; break;
+        case 1: promo = tc == 3 * R / 4; break;
+        case 2: promo = tr == 3 * R / 4; break;
+        default: promo = tc == R / 4; break;
+      }
+      if (promo) piece = (uint8_t)(0x80 | (pc << 5) | (QUEEN << 2));
+    } else if (ty == KING) {
+      const int dr = tr - fr, dc = tc - fc;
+      if ((dr == 0 && (dc == 2 || dc == -2)) || (dc == 0 && (dr == 2 || dr == -2))) {   // castling: the rook hops next to the king
+        const int ur = dr / 2, uc = dc / 2;
+        // kingside: rook 3 squares from the king, queenside: 4 (engine/board.cpp:343-465)
+        for (int d = 3; d <= 4; ++d) {
+          const int rr = fr + ur * d, rc = fc + uc * d;
+          if (in_array(c, rr, rc)) {
+            const uint8_t rk = b->sq[rr * R + rc];
+            if (present(rk) && type_of(rk) == ROOK && colour_of(rk) == pc) { rook_from = rr * R + rc; rook_to = (fr + ur) * R + fc + uc; break; }
+            if (present(rk)) break;
+          }
+        }
+      }
+      b->castle[pc] = 0;
+    } else if (ty == ROOK && b->castle[pc]) {
+      int ks, qs;      // rook home squares, engine/board.cpp:256-289
+      switch (pc) {
+        case 0: ks = (R - 1) * R + (R - 4); qs = (R - 1) * R + c.INV; break;
+        case 1: ks = (R - 4) * R; qs = c.INV * R; break;
+        case 2: ks = c.INV; qs = R - 4; break;
+        default: ks = c.INV * R + (R - 1); qs = (R - 4) * R + (R - 1); break;
+      }
+      if (from == ks) b->castle[pc] &= (uint8_t)~1u;
+      if (from == qs) b->castle[pc] &= (uint8_t)~2u;
+    }
+  }
   {  // RemovePiece(from) + SetPiece(to, piece)
     uint8_t *l = b->pl[pc];
     int n = b->plen[pc], i = 0;
@@ -200,6 +256,12 @@ __device__ __forceinline__ bool make_move_lane0(fpc_board *b, int from, int to) 
     b->sq[from] = 0;
     b->sq[to] = piece;
     if (type_of(piece) == KING) b->king[pc] = (uint8_t)to;
+  }
+  if (rook_from != FPC_NO_SQ) {   // RemovePiece(rook_from) + SetPiece(rook_to): the rook's entry follows the king's
+    list_move_to_end(b->pl[pc], b->plen[pc], rook_from);
+    b->pl[pc][b->plen[pc] - 1] = (uint8_t)rook_to;
+    b->sq[rook_to] = b->sq[rook_from];
+    b->sq[rook_from] = 0;
   }
   b->turn = (uint8_t)((b->turn + 1) & 3);  // GetNextPlayer, engine/board.cpp:1299-1313
   return true;
@@ -625,7 +687,7 @@ __global__ void __launch_bounds__(64) k_board_ops(DevCfg c, fpc_board *boards, i
     if (lane == 0) {
       int from;
       const int to = flat_to(c, flat[g], &from);
-      s.errbits = make_move_lane0(&s.b, from, to) ? 0 : ERR_MOVE;
+      s.errbits = make_move_lane0(&s.b, from, to, c) ? 0 : ERR_MOVE;
     }
     __syncthreads();
     e |= s.errbits;
@@ -677,18 +739,19 @@ __global__ void __launch_bounds__(64) k_encode(DevCfg c, const fpc_board *boards
   if (g >= G) return;
   const int lane = lane_id();
   const int slot = slot_of ? slot_of[g] : 0;   // for the search: leaf board slot (or -1 dead)
-  const int k = fixed_rot >= 0 ? fixed_rot : first_leaf_turn(slot_of, leaf_turn, G);
   const int R = c.R, RR = c.RR;
   const bool live = slot >= 0;
   const fpc_board *b = live ? &boards[(size_t)g * board_stride + slot] : nullptr;
   const int turn = live ? b->turn : 0;
+  // batch-wide rotation by the first state's turn (Q6); FPC_RULES_ROTATION: every sample by its own turn
+  const int k = (c.rules & FPC_RULES_ROTATION) ? turn : (fixed_rot >= 0 ? fixed_rot : first_leaf_turn(slot_of, leaf_turn, G));
   if (mode == 0) {
     float *o = out_f32 + (size_t)g * 24 * RR;
     for (int pos = lane; pos < RR; pos += 64) {
       int plane = -1;
       if (live) {
         const uint8_t p = b->sq[rot90_src(R, k, pos / R, pos % R)];
-        if (present(p)) { plane = 6 * ((colour_of(p) - turn) & 3) + type_of(p) - 1; if (plane < 0) plane += 24; }
+        if (present(p)) plane = piece_plane(p, turn, c.rules);
       }
       for (int pl = 0; pl < 24; ++pl) o[(size_t)pl * RR + pos] = pl == plane ? 1.0f : 0.0f;
     }
@@ -700,7 +763,7 @@ __global__ void __launch_bounds__(64) k_encode(DevCfg c, const fpc_board *boards
       const int i = pos / R, j = pos % R;
       if (live) {
         const uint8_t p = b->sq[rot90_src(R, k, i, j)];
-        if (present(p)) { plane = 6 * ((colour_of(p) - turn) & 3) + type_of(p) - 1; if (plane < 0) plane += 24; }
+        if (present(p)) plane = piece_plane(p, turn, c.rules);
       }
       uint32_t *row = reinterpret_cast<uint32_t *>(o + ((size_t)(i + 1) * P + (j + 1)) * 32);
       for (int w = 0; w < 16; ++w) {
@@ -848,6 +911,7 @@ __global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double C
     if (c0 < 0) break;
     const int nc = t.nch[nb + n];
     const double L = logtab[t.N[nb + n]];
+    const double sqrtNp = sqrt((double)t.N[nb + n]);
     double best = 0.0;
     int besti = -1;
     for (int base = 0; base < nc; base += 64) {
@@ -858,9 +922,15 @@ __global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double C
         const int Nc = t.N[nb + c0 + i];
         const double Wc = t.W[nb + c0 + i];
         const double Pc = (double)t.P[nb + c0 + i];
-        const double q = Nc > 0 ? Wc / (double)Nc : 0.0;
-        const double e = Cpuct * sqrt(L / (double)(1 + Nc));
-        u = q + e * Pc;
+        if (c.rules & FPC_RULES_PUCT) {
+          // AlphaZero PUCT, the child's value seen from the parent: -W/N + C P sqrt(N_parent) / (1 + N)
+          const double q = Nc > 0 ? -(Wc / (double)Nc) : 0.0;
+          u = q + Cpuct * Pc * sqrtNp / (double)(1 + Nc);
+        } else {
+          const double q = Nc > 0 ? Wc / (double)Nc : 0.0;
+          const double e = Cpuct * sqrt(L / (double)(1 + Nc));
+          u = q + e * Pc;
+        }
         valid = u > -__builtin_inf();
       }
       int idx = valid ? i : 0x7fffffff;
@@ -889,7 +959,7 @@ __global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double C
     if (lane == 0) {
       int from;
       const int to = flat_to(c, t.mv[nb + n], &from);
-      int e = make_move_lane0(&s.b, from, to) ? 0 : ERR_MOVE;
+      int e = make_move_lane0(&s.b, from, to, c) ? 0 : ERR_MOVE;
       int ns = t.nboards[g];
       if (ns >= t.board_cap) { e |= ERR_CAP_BOARDS; ns = -1; } else { t.nboards[g] = ns + 1; t.bslot[nb + n] = ns; }
       s.first_legal = ns;                    // broadcast through LDS
@@ -978,6 +1048,20 @@ __device__ __forceinline__ void expand_finish(WaveLds &s, const Tree &t, int g, 
     return;
   }
   const float T = s.scal_f;
+  // root Dirichlet noise (N4): prior' = (1 - eps) prior + eps g_j / sum g over the root's legal moves,
+  // g = caller-supplied Gamma(alpha) draws; sequential ascending f32 sum, IEEE division
+  const bool noisy = n == 0 && t.noise != nullptr;
+  if (noisy) {
+    const float *gm = t.noise + (size_t)g * FPC_MAX_MOVES;
+    __syncthreads();
+    if (lane == 0) {
+      float sg = 0.f;
+      for (int j = 0; j < nl; ++j) sg = sg + gm[j];
+      s.scal_f = sg;
+    }
+    __syncthreads();
+  }
+  const float SG = s.scal_f;
   // BackpropagateNodes (mcts.py:78) before ExpandNodes (mcts.py:79)
   backprop_path(t, nb, g, value[g]);
   if (lane == 0) t.sims_done[g] += 1;
@@ -988,7 +1072,11 @@ __device__ __forceinline__ void expand_finish(WaveLds &s, const Tree &t, int g, 
     const int j = b0 + lane;
     float pr = 0.f;
     bool nz = false;
-    if (j < nl) { pr = fdiv_rn(s.pri[j], T); nz = pr != 0.f; }
+    if (j < nl) {
+      pr = fdiv_rn(s.pri[j], T);
+      if (noisy) pr = (1.0f - t.noise_eps) * pr + t.noise_eps * fdiv_rn(t.noise[(size_t)g * FPC_MAX_MOVES + j], SG);
+      nz = pr != 0.f;
+    }
     const unsigned long long bal = __ballot(nz);
     if (nz) {
       const int k = base_node + created + __popcll(bal & ((1ull << lane) - 1ull));
@@ -1026,8 +1114,8 @@ __global__ void __launch_bounds__(EXPAND_THREADS) k_expand(DevCfg c, Tree t, int
   const int g = blockIdx.x;
   if (g >= G) return;
   const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-  const int turn0 = first_leaf_turn(t.leaf_node, t.leaf_turn, G);
   const int n = t.leaf_node[g];
+  const int turn0 = (c.rules & FPC_RULES_ROTATION) ? t.leaf_turn[g] : first_leaf_turn(t.leaf_node, t.leaf_turn, G);
   if (n < 0) return;
   const size_t nb = (size_t)g * t.node_cap;
   const float *lg = logits + (size_t)g * c.A;

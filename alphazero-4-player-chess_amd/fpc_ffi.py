@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FPC_ENGINE_LIB") or os.path.join(HERE, "csrc", "libfpc_engine.so")
 
 MAX_SQ, MAX_PL, NO_SQ, MAX_MOVES = 196, 16, 255, 256
+RULES_STRICT, RULES_PUCT, RULES_ROTATION, RULES_PLANES, RULES_FULL_MOVES, RULES_FIXED = 0, 1, 2, 4, 8, 15
 
 
 class Board(C.Structure):
@@ -85,6 +86,8 @@ _SIGS = {
     "fpc_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "fpc_set_policy_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "fpc_stream": (C.c_void_p, [C.c_void_p]),
+    "fpc_set_rules": (C.c_int, [C.c_void_p, C.c_int]),
+    "fpc_search_set_root_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float]),
     "fpc_tuples_reserve": (C.c_int, [C.c_void_p, C.c_int]),
     "fpc_tuples_reset": (C.c_int, [C.c_void_p]),
     "fpc_collect_tuples": (C.c_int, [C.c_void_p, P(C.c_int), C.c_int]),
@@ -292,6 +295,20 @@ class Engine:
 
     def set_timing(self, on):
         self.L.fpc_set_timing(self.h, 1 if on else 0)
+
+    # ---- N4: non-strict rule set and root Dirichlet noise (include/fpc_engine.h FPC_RULES_*) ----
+    def set_rules(self, rules):
+        """0 = strict reference semantics (default); RULES_FIXED = all corrections"""
+        self._chk(self.L.fpc_set_rules(self.h, int(rules)))
+
+    def set_root_noise(self, gamma, eps):
+        """gamma: float32 array [n_games, MAX_MOVES] of Gamma(alpha) draws (None: off)"""
+        if gamma is None:
+            self._chk(self.L.fpc_search_set_root_noise(self.h, None, 0, 0.0))
+            return
+        g = np.ascontiguousarray(gamma, dtype=np.float32)
+        assert g.ndim == 2 and g.shape[1] == MAX_MOVES
+        self._chk(self.L.fpc_search_set_root_noise(self.h, g.ctypes.data, g.shape[0], float(eps)))
 
     # ---- training tuples (device resident) and their RCCL exchange ----
     def tuples_reserve(self, capacity):

@@ -44,6 +44,15 @@ class MCTS:
         # simulations/s at 14x14; include/fpc_engine.h fpc_set_policy_mode)
         self.policy_head = str(args.get("policy_head", "full")) if hasattr(args, "get") else "full"
         self._native = _is_resnet(neural_net)
+        # N4 (explicitly NOT part of parity with the reference): args["rules"] = "strict"
+        # (default: every quirk of the reference, bit-exact) or "fixed" (AlphaZero PUCT with the child's value
+        # negated, per-sample rotation, un-shifted input planes, full moves in the tree), or an int of
+        # fpc_ffi.RULES_* bits; args["root_noise"] = True applies Dirichlet(dirichlet_alpha) noise with weight
+        # dirichlet_epsilon to the root priors inside the fused search loop, seeded by args["noise_seed"].
+        rules = args.get("rules", "strict") if hasattr(args, "get") else "strict"
+        self.rules = {"strict": 0, "fixed": 15}.get(rules, rules)
+        self.root_noise = bool(args.get("root_noise", False)) if hasattr(args, "get") else False
+        self._noise_rng = np.random.default_rng(int(args.get("noise_seed", 0))) if self.root_noise else None
 
     def sync_weights(self, eng):
         """(re-)export the network into the engine when its parameters changed (optimizer.step)."""
@@ -70,6 +79,13 @@ class MCTS:
         sims = int(self.args["num_searches"])
         eng = az.engine(G, sims, self.nn_dtype if self._native else None)
         pods = [g._b for g in games]
+        eng.set_rules(int(self.rules))
+        if self.root_noise:
+            import fpc_ffi
+            gamma = self._noise_rng.standard_gamma(float(self.args["dirichlet_alpha"]), size=(G, fpc_ffi.MAX_MOVES)).astype(np.float32)
+            eng.set_root_noise(gamma, float(self.args["dirichlet_epsilon"]))
+        else:
+            eng.set_root_noise(None, 0.0)
         eng.search_begin(pods, float(self.args["C"]))
         if self._native:
             self.sync_weights(eng)

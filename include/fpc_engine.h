@@ -147,6 +147,25 @@ int fpc_search_run(fpc_engine *e, int sims);
  *                    below the global maximum (FULL flushes that child to zero).  Opt-in. */
 enum { FPC_POLICY_FULL = 0, FPC_POLICY_LEGAL = 1 };
 int fpc_set_policy_mode(fpc_engine *e, int mode);
+/* ---- N4: root Dirichlet noise and the non-strict ("fixed") rule set ---------------
+ * Strict reference semantics (every quirk of SURVEY 8a-Q, bit-exact with the reference) are the default.
+ * fpc_set_rules switches individual corrections on for real training runs; none of them is covered by a
+ * parity claim against the reference -- they are held against the oracle running the same rule set. */
+enum {
+  FPC_RULES_STRICT = 0,
+  FPC_RULES_PUCT = 1,        /* Q2 + Q3: U = C P sqrt(N_parent) / (1 + N), child value seen from the parent (-W/N)   node.cpp:53-63 */
+  FPC_RULES_ROTATION = 2,    /* Q6: every sample is rotated by its OWN side to move (encode and policy decode)       board.cpp:322,354-355 */
+  FPC_RULES_PLANES = 4,      /* Q7: input plane 6*rel_colour + type, no -1 wrap                                       board.cpp:336 */
+  FPC_RULES_FULL_MOVES = 8,  /* Q9: tree/self-play moves promote (to a queen), hop the rook when castling, update rights  node.cpp:87-92 */
+  FPC_RULES_FIXED = 15
+};
+int fpc_set_rules(fpc_engine *e, int rules);
+/* Root noise for the NEXT searches (mcts.py:45-56 defines add_dirichlet_noise and never calls it):
+ * prior'_j = (1 - eps) prior_j + eps g_j / sum_k g_k over the root's legal moves j in ascending flat order,
+ * gamma: host array [n_games][FPC_MAX_MOVES] of Gamma(alpha, 1) draws made (and seeded) by the caller;
+ * NULL switches the noise off. */
+int fpc_search_set_root_noise(fpc_engine *e, const float *gamma, int n_games, float eps);
+
 /* Root read-back == what alphazero.py:104-110 reads through Node.GetChildren /
  * GetMoveMade().GetFlatIndex() / GetVisitCount().  Arrays are [n_games][max_children].
  * roots_out (nullable): the root states with the piece-list order the search left them in. */

@@ -490,7 +490,19 @@ int rot90_src(int R, int k, int i, int j) {
 
 }  // namespace
 
+// ---- N4: the non-strict rule set and root noise, same definitions as include/fpc_engine.h FPC_RULES_* ----
+namespace {
+enum { RULES_PUCT = 1, RULES_ROTATION = 2, RULES_PLANES = 4, RULES_FULL_MOVES = 8 };
+int g_rules = 0;
+const float *g_noise = nullptr;   // [G][noise_stride] gamma draws per root child (ascending flat order)
+int g_noise_stride = 0;
+float g_noise_eps = 0.f;
+}
+
 extern "C" {
+
+void orc_set_rules(int rules) { g_rules = rules; }
+void orc_set_root_noise(const float *gamma, int stride, float eps) { g_noise = gamma; g_noise_stride = stride; g_noise_eps = eps; }
 
 int orc_action_channels(int R) { return 4 * R + 4 * R + 8; }                 // board.cpp:11
 int orc_action_size(int R) { return orc_action_channels(R) * R * R; }        // board.cpp:12
@@ -563,6 +575,17 @@ int orc_take_action_flat(orc_board *b, int R, int flat) {   // board.cpp:234-239
   int from, to;
   orc_flat_to_move(R, flat, &from, &to);
   orc_move m = mk_move(from, to, 0);
+  if (g_rules & RULES_FULL_MOVES) {
+    // the move as the generator describes it (queen promotion, rook hop, castling rights): the last
+    // generated move with this (from, to) -- promotions are emitted N, B, R, Q (engine/board.cpp:82-88)
+    const int INV = R == 8 || R == 10 ? 2 : 3;
+    orc_move buf[300];
+    orc_board tmp = *b;
+    tmp.turn = (uint8_t)colour_of(b->sq[from]);
+    const int n = present(b->sq[from]) ? pseudo_legal(&tmp, R, INV, buf, 300) : 0;
+    for (int i = 0; i < n; ++i)
+      if (buf[i].from == from && buf[i].to == to) m = buf[i];
+  }
   return make_move(b, &m);
 }
 
@@ -588,6 +611,7 @@ void orc_encode(const orc_board *boards, int n, int R, float *out) {
   int k = n > 0 ? boards[0].turn : 0;  // batch-wide rotation by states[0] (quirk Q6)
   for (int bi = 0; bi < n; ++bi) {
     const orc_board *b = &boards[bi];
+    if (g_rules & RULES_ROTATION) k = b->turn;
     std::fill(tmp.begin(), tmp.end(), 0.f);
     for (int c = 0; c < 4; ++c)
       for (int i = 0; i < b->plen[c]; ++i) {
@@ -595,6 +619,7 @@ void orc_encode(const orc_board *boards, int n, int R, float *out) {
         uint8_t p = b->sq[sq];
         int off = 6 * ((colour_of(p) - b->turn + 4) & 3);
         int plane = off + type_of(p) - 1;    // :336; -1 wraps to plane 23 (index_put_ negative index, Q7)
+        if (g_rules & RULES_PLANES) plane = off + type_of(p);
         if (plane < 0) plane += 24;
         tmp[(size_t)plane * RR + sq] = 1.f;
       }
@@ -711,6 +736,10 @@ int orc_search(orc_board *boards, int G, int R, int INV, int sims, double Cpuct,
           const ONode &ch = t[nd.children[i]];
           double cv = ch.visit_count > 0 ? ch.value_sum / ch.visit_count : 0;
           double ucb = cv + Cpuct * std::sqrt(lp / (1 + ch.visit_count)) * ch.prior;
+          if (g_rules & RULES_PUCT) {
+            const double q = ch.visit_count > 0 ? -(ch.value_sum / (double)ch.visit_count) : 0.0;
+            ucb = q + Cpuct * ch.prior * std::sqrt((double)nd.visit_count) / (double)(1 + ch.visit_count);
+          }
           if (ucb > best_ucb) { best = (int)i; best_ucb = ucb; }
         }
         if (best < 0) { rc = -2; goto done; }  // node.cpp:72-75 throws
@@ -744,8 +773,15 @@ int orc_search(orc_board *boards, int G, int R, int INV, int sims, double Cpuct,
       std::sort(legal[i].begin(), legal[i].end());
       legal[i].erase(std::unique(legal[i].begin(), legal[i].end()), legal[i].end());
       pri[i].resize(legal[i].size());
-      if (orc_policy_priors(&logits[(size_t)i * A], R, turn0, legal[i].data(), (int)legal[i].size(), pri[i].data())) {
+      const int rot = (g_rules & RULES_ROTATION) ? leaf_states[i].turn : turn0;
+      if (orc_policy_priors(&logits[(size_t)i * A], R, rot, legal[i].data(), (int)legal[i].size(), pri[i].data())) {
         rc = -3; goto done;
+      }
+      if (g_noise && leaf_node[i] == 0) {              // root Dirichlet noise (N4), same arithmetic as the engine
+        const float *gm = g_noise + (size_t)leaf_game[i] * g_noise_stride;
+        float sg = 0.f;
+        for (size_t k2 = 0; k2 < legal[i].size(); ++k2) sg = sg + gm[k2];
+        for (size_t k2 = 0; k2 < legal[i].size(); ++k2) pri[i][k2] = (1.0f - g_noise_eps) * pri[i][k2] + g_noise_eps * (gm[k2] / sg);
       }
     }
     for (int i = 0; i < B; ++i) {                       // mcts.py:78, node.cpp:144-154

@@ -54,6 +54,9 @@ typedef struct orc_move {        /* chess::Move, engine/board.h:330-436 */
 typedef void (*orc_eval_fn)(void *user, const float *enc, int B, float *logits, float *value);
 
 /* ---- geometry / codec (board.cpp:9-14, move.cpp:13-104) ---- */
+/* N4: non-strict rule set (bits as FPC_RULES_* in include/fpc_engine.h) and root noise; 0 / NULL = the reference */
+void orc_set_rules(int rules);
+void orc_set_root_noise(const float *gamma, int stride, float eps);
 int orc_action_channels(int R);              /* 4R+4C+8 */
 int orc_action_size(int R);                  /* A_ch*R*R */
 int orc_is_legal_location(int R, int INV, int row, int col);

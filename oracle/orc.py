@@ -51,6 +51,8 @@ def lib():
         L.orc_search.argtypes = [C.POINTER(Board), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p,
                                  C.c_void_p, C.POINTER(SearchOut), C.c_int, C.POINTER(C.c_int),
                                  C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)]
+        L.orc_set_rules.argtypes = [C.c_int]
+        L.orc_set_root_noise.argtypes = [C.c_void_p, C.c_int, C.c_float]
         L.orc_policy_priors.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int,
                                         C.POINTER(C.c_float)]
         _lib = L
@@ -76,6 +78,26 @@ def board_from_dict(R, turn, entries, castle=None):
     cs = (C.c_uint8 * 4)(*castle) if castle else None
     lib().orc_board_from_dict(C.byref(b), R, turn, sqs, pcs, n, cs)
     return b
+
+
+def set_rules(rules):
+    """N4: non-strict rule set, bits as FPC_RULES_* (0 = the reference)"""
+    lib().orc_set_rules(int(rules))
+
+
+_noise_keep = None
+
+
+def set_root_noise(gamma, eps=0.0):
+    """gamma: float32 [G, stride] Gamma(alpha) draws per root child (None: off)"""
+    global _noise_keep
+    import numpy as np
+    if gamma is None:
+        _noise_keep = None
+        lib().orc_set_root_noise(None, 0, C.c_float(0.0))
+        return
+    _noise_keep = np.ascontiguousarray(gamma, dtype=np.float32)
+    lib().orc_set_root_noise(_noise_keep.ctypes.data_as(C.c_void_p), _noise_keep.shape[1], C.c_float(float(eps)))
 
 
 def lists_of(b):

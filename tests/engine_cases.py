@@ -393,3 +393,75 @@ def case_arena_vs_oracle(backend, R, n_pairs=3, sims=24, max_len=30, seed=9, kin
     assert s["games"] == 2 * n_pairs and abs(s["score_a"] + s["score_b"] - s["games"]) < 1e-9
     eng.close()
     return n_plies
+
+
+def case_fixed_rules_vs_oracle(backend, R, n_games=6, plies=60, sims=40, seed=31, rules=15, noise=True):
+    """SURVEY 8f N4 -- NOT part of parity with the reference: the non-strict rule set (FPC_RULES_FIXED:
+    AlphaZero PUCT with the child's value negated, per-sample rotation, un-shifted input planes, full
+    moves = queen promotion / rook hop / castling rights) and root Dirichlet noise, engine against the
+    oracle running the same rules: boards after every move, encodes, and searches bit for bit."""
+    import random
+    import positions
+    INV = {8: 2, 10: 2, 13: 3, 14: 3}[R]
+    turn, entries = positions.start_entries(R)
+    castle = [3, 3, 3, 3] if R == 14 else None
+    if R == 14:     # rooks, kings and pawns only, all rights set: castling becomes reachable
+        entries = [e for e in entries if e[2] in (positions.PAWN, positions.ROOK, positions.KING)]
+    rng = random.Random(seed)
+    eng = make_engine(backend, R, INV, max_games=n_games, max_sims=sims)
+    n_promo = n_castle = 0
+    try:
+        orc.set_rules(rules)
+        eng.set_rules(rules)
+        roots_o = []
+        for _ in range(n_games):
+            b = orc.board_from_dict(R, turn, [list(e) for e in entries], castle=castle)
+            fb = fpc_ffi.board_from_dict(R, turn, entries, castle=castle, _lib=eng.L)
+            for _ply in range(rng.randrange(plies // 2, plies)):
+                if orc.game_result(b, R, INV) != 0:
+                    break
+                eng.game_result([fb])
+                lm_o = orc.legal_moves(b, R, INV)
+                lm_e = expand_promos(eng.legal_moves([fb])[0])
+                assert lm_e == lm_o
+                flats = sorted(set(x[2] for x in lm_o))
+                kings = [b.king[c] for c in range(4)]
+                castles = [m for m in lm_o if m[0] in kings and max(abs(m[0] // R - m[1] // R), abs(m[0] % R - m[1] % R)) == 2]
+                pick = castles[0][2] if castles and rng.random() < 0.7 else flats[rng.randrange(len(flats))]
+                n_castle += bool(castles and pick == castles[0][2])
+                queens_before = sum(1 for c in range(4) for i in range(b.plen[c]) if ((b.sq[b.pl[c][i]] >> 2) & 7) == 4)
+                b, rc = orc.take_action(b, R, pick)
+                fb = eng.take_action([fb], [pick])[0]
+                assert rc == 0
+                n_promo += sum(1 for c in range(4) for i in range(b.plen[c]) if ((b.sq[b.pl[c][i]] >> 2) & 7) == 4) > queens_before
+                assert bytes(fb.sq) == bytes(b.sq) and fpc_ffi.lists_of(fb) == orc.lists_of(b), (_ply, pick)
+                assert [fb.castle[c] for c in range(4)] == [b.castle[c] for c in range(4)] and fb.turn == b.turn
+                assert np.array_equal(eng.encode([fb]), orc.encode([b], R))
+            if orc.game_result(orc.clone(b), R, INV) != 0:
+                b = orc.board_from_dict(R, turn, [list(e) for e in entries], castle=castle)
+            roots_o.append(b)
+        ev = evaluators.make("hash", R)
+        gamma = None
+        if noise:
+            gamma = np.random.default_rng(seed).standard_gamma(0.3, size=(n_games, fpc_ffi.MAX_MOVES)).astype(np.float32)
+            orc.set_root_noise(gamma, 0.25)
+            eng.set_root_noise(gamma, 0.25)
+        rc, oref = orc.search([orc.clone(b) for b in roots_o], R, INV, sims, 3.0, ev)
+        assert rc == 0
+        roots = []
+        for b in roots_o:
+            fb = fpc_ffi.board_from_lists(R, b.turn, orc.lists_of(b))
+            for c in range(4):
+                fb.castle[c] = b.castle[c]
+            roots.append(fb)
+        res = run_external_search(eng, backend, roots, sims, 3.0, ev)
+        _compare_search(res, oref, ("fixed", R, rules))
+        if noise:      # the noise really entered: strict-rule priors differ
+            eng.set_root_noise(None, 0.0)
+            res2 = run_external_search(eng, backend, [fpc_ffi.clone_board(r) for r in roots], sims, 3.0, ev)
+            assert not np.array_equal(res["prior"], res2["prior"])
+    finally:
+        orc.set_rules(0)
+        orc.set_root_noise(None)
+        eng.close()
+    return n_promo, n_castle

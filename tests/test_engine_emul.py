@@ -49,3 +49,10 @@ def test_castling_vs_oracle():
 def test_arena_vs_oracle():
     """configs[4]: paired temperature-0 arena games, engine vs oracle, every ply bit-exact"""
     assert ec.case_arena_vs_oracle("emul", 8, n_pairs=2, sims=16, max_len=14) > 20
+
+
+@pytest.mark.parametrize("R", [8, 14])
+def test_fixed_rules_and_root_noise_vs_oracle(R):
+    """N4: non-strict rule set + root Dirichlet noise, engine vs oracle under the same rules"""
+    n_promo, n_castle = ec.case_fixed_rules_vs_oracle("emul", R, n_games=3, plies=70 if R == 8 else 30, sims=16)
+    assert (n_promo > 0) if R == 8 else (n_castle > 0)

@@ -54,3 +54,12 @@ def test_castling_vs_oracle():
 def test_arena_vs_oracle(R, pairs, sims, max_len):
     """configs[4]: paired temperature-0 arena games, engine vs oracle, every ply bit-exact"""
     assert ec.case_arena_vs_oracle("gpu", R, n_pairs=pairs, sims=sims, max_len=max_len) > 100
+
+
+@pytest.mark.parametrize("R,rules", [(8, 15), (14, 15), (8, 1), (14, 6)])
+def test_fixed_rules_and_root_noise_vs_oracle(R, rules):
+    """N4 (outside parity with the reference): non-strict rule set + root Dirichlet noise inside the
+    search loop, HIP engine vs the oracle running the same rules, bit for bit"""
+    n_promo, n_castle = ec.case_fixed_rules_vs_oracle("gpu", R, n_games=12, plies=90 if R == 8 else 40, sims=60, rules=rules)
+    if rules & 8:
+        assert (n_promo > 0) if R == 8 else (n_castle > 0)

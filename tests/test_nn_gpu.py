@@ -131,16 +131,20 @@ def test_resnet_forward_more_than_256_rows():
     eng.close()
 
 
-@pytest.mark.parametrize("R,dtype", [(8, 0), (14, 1)])
-def test_fused_search_equals_stepwise(R, dtype):
+@pytest.mark.parametrize("R,dtype,rules", [(8, 0, 0), (14, 1, 0), (14, 1, 15), (8, 1, 15)])
+def test_fused_search_equals_stepwise(R, dtype, rules):
     """fpc_search_run (encode->MFMA net->expand, no host round trip) must give exactly the visit
-    counts of the step-wise path fed with the same network's outputs."""
+    counts of the step-wise path fed with the same network's outputs -- under the strict rules and
+    under the non-strict rule set with root noise (N4: fused encode / decode rotations, plane numbering)."""
     import torch
     import weights
     m = _model(R, 2, 64, seed=3)
     G, sims = 12, 48
     eng = make_engine("gpu", R, gold(R)["INV"], max_games=G, max_sims=sims, nn_dtype=dtype)
     eng.load_weights(weights.export_weights(m, dtype))
+    eng.set_rules(rules)
+    if rules:
+        eng.set_root_noise(np.random.default_rng(7).standard_gamma(0.3, size=(G, fpc_ffi.MAX_MOVES)).astype(np.float32), 0.25)
     boards = _positions(R, G)
     roots_a = [fpc_ffi.clone_board(b) for b in boards]
     eng.search_begin(roots_a, 3.0)

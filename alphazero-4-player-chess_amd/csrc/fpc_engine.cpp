@@ -715,6 +715,9 @@ struct Id128 { char b[128]; };    // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 
 Rccl &rccl() {
   static Rccl r;
   if (r.h || !r.err.empty()) return r;
+  // FPC_RCCL_LIB: the host layer names the copy that belongs to the HIP runtime already in the process
+  // (PyTorch-ROCm ships its own librccl.so next to its libamdhip64.so)
+  if (const char *env = getenv("FPC_RCCL_LIB")) r.h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
   const char *names[] = {"librccl.so", "librccl.so.1"};
   for (const char *n : names) if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
   for (const char *n : names) if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);

@@ -127,6 +127,9 @@ def lib():
         # seam, torch.distributed), not a compute path.
         try:
             import torch  # noqa: F401
+            rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            if os.path.exists(rccl):
+                os.environ.setdefault("FPC_RCCL_LIB", rccl)    # fpc_comm_*: the RCCL that matches this HIP runtime
         except ImportError:
             pass
         _lib = bind(C.CDLL(LIB_PATH))

@@ -198,8 +198,15 @@ def main():
         recs = tuples_mod.exchange(eng)
         return len(recs) * 1280
 
-    if world > 1 and args.backend == "nccl":
-        tuples_mod.init_comm(eng, device=torch.device("cuda", local))
+    exchange_path = "single process"
+    if world > 1:
+        exchange_path = "torch.distributed all_gather of the native tuple PODs (%s)" % args.backend
+        if args.backend == "nccl":
+            try:      # the engine's own RCCL communicator (C++ host); its 128-byte id travels over torch.distributed
+                tuples_mod.init_comm(eng, device=torch.device("cuda", local))
+                exchange_path = "fpc_allgather_tuples: ncclAllGather issued by the engine's C++ host"
+            except RuntimeError as exc:
+                exchange_path += " [fpc_comm_init failed: %s]" % (exc,)
 
     for _ in range(args.warmup):
         step(False)
@@ -316,7 +323,7 @@ def main():
         "config": {"workload": "configs[1]: %d concurrent games/GPU x %d sims/move, ResNet(%d,%d), %dx%d board, start=%s"
                    % (G, sims, args.blocks, args.hidden, R, R, "STANDARD" if R == 14 else "default"),
                    "games_per_gpu": G, "sims_per_move": sims, "board": R, "parallelism": "games sharded, %d/GPU" % G,
-                   "tuple_allgather_bytes": gathered},
+                   "tuple_allgather_bytes": gathered, "tuple_exchange": exchange_path},
         # dominant kernel: k_tower = stem + 2*Nb residual convs + both head convs, one launch per network forward
         "roofline": {"bound": "mfma", "achieved": ach_tower, "peak": peak, "unit": "TFLOP/s", "frac": ach_tower / peak,
                      "traffic": pmc.get("k_tower", {}).get("hbm_bytes"),

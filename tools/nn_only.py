@@ -11,8 +11,9 @@ from bench import Spec
 R, G, iters = 14, 256, int(sys.argv[1]) if len(sys.argv) > 1 else 5
 torch.manual_seed(0)
 m = net.ResNet(Spec(R), 10, 128, "cpu").eval()
-eng = fpc_ffi.Engine(R, 3, max_games=G, max_sims=8)
-eng.load_weights(weights.export_weights(m, 0))
+DT = int(os.environ.get("FPC_NN_DTYPE", "1"))   # 1 = fp16 (the headline operand type), 0 = bf16
+eng = fpc_ffi.Engine(R, 3, max_games=G, max_sims=8, nn_dtype=DT)
+eng.load_weights(weights.export_weights(m, DT))
 x = (torch.rand(G, 24, R, R) < 0.1).float().cuda()
 lg = torch.empty(G, eng.A, device="cuda"); va = torch.empty(G, device="cuda")
 import time

@@ -4,9 +4,10 @@ profiles/pmc_summary.json: per kernel, averages per launch.  HBM bytes follow th
 recipe: FETCH_SIZE (KB) counts wide coalesced reads at half -> doubled; WRITE_SIZE (KB) exact."""
 import collections, csv, glob, json, os, sys
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "gpurun_out")
+# usage: pmc_summary.py <dir holding pmc_a.csv .. pmc_f.csv> (tools/profile_round.sh copies them there)
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "gpurun_out", "r02")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
+for f in sorted(glob.glob(os.path.join(src, "pmc_?.csv"))):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         k = k.split("(")[0].split("::")[-1].split("<")[0]

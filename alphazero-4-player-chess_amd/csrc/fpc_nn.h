@@ -25,6 +25,7 @@
 
 #include "fpc_tree_kernels.h"
 #include "fpc_tower.h"
+#include "fpc_tower256.h"
 
 namespace fpc {
 
@@ -432,12 +433,13 @@ struct NN {
   unsigned char *towerW = nullptr;   // k_tower's weight stream: [(2*nblocks + 2) * 9 taps][32 KiB] in LDS-image order (F == 128)
   unsigned char *stemW = nullptr;    // [9 taps][8 KiB], same order
   float *towerB = nullptr;           // [2*nblocks + 2][256] (128 used)
-  bool use_tower = false;
+  bool use_tower = false;            // hidden == 128: k_tower
+  bool use_tower256 = false;         // hidden == 256 on the 14x14 board: k_tower256
   void (*mark_fn)(void *, int) = nullptr;   // stage-timing hook of the engine (tag 2 = policy Linear starts)
   void *mark_ctx = nullptr;
   float vb = 0.f;
   // dynamic-LDS opt-ins (hipFuncSetAttribute) already made for this engine's device
-  bool attr_conv[2][3] = {{false, false, false}, {false, false, false}}, attr_tower[2] = {false, false}, attr_fc[2] = {false, false}, attr_gemv = false;
+  bool attr_conv[2][3] = {{false, false, false}, {false, false, false}}, attr_tower[2] = {false, false}, attr_tower256[2] = {false, false}, attr_fc[2] = {false, false}, attr_gemv = false;
 
   template <class T>
   int dmalloc(T **p, size_t count, std::string *err) {
@@ -467,7 +469,7 @@ struct NN {
   const fpc_board *in_boards = nullptr;
   const int *in_leaf_slot = nullptr, *in_leaf_turn = nullptr;
   int in_board_stride = 0;
-  bool takes_boards() const { return use_tower; }
+  bool takes_boards() const { return use_tower || use_tower256; }
   void set_board_input(const fpc_board *b, int stride, const int *slot, const int *turn) { in_boards = b; in_board_stride = stride; in_leaf_slot = slot; in_leaf_turn = turn; }
   uint16_t one16() const { return dtype ? 0x3C00 : 0x3F80; }
   float *logits() { return d_logits; }
@@ -574,6 +576,25 @@ struct NN {
       if (hipStreamSynchronize(stream) != hipSuccess) { *err = "k_tower_prep failed"; return FPC_ENODEVICE; }
       use_tower = true;
     }
+    use_tower256 = false;
+    if (F == 256 && dc.R == 14 && !getenv("FPC_NO_TOWER")) {
+      // k_tower256 streams one 16 KiB slab per k-step ([256 cout][32 cin], LDS-image order, fpc_tower256.h);
+      // head convolutions are zero-padded to 256 output channels
+      const int layers = 2 * nblocks + 2;
+      if ((rc = dmalloc(&towerW, (size_t)layers * 9 * T2_KS * T2_SLAB, err)) || (rc = dmalloc(&stemW, (size_t)9 * T2_SLAB, err)) ||
+          (rc = dmalloc(&towerB, (size_t)layers * 256, err))) return rc;
+      auto prep = [&](const ConvW &cw, int layer) {
+        hipLaunchKernelGGL(k_tower256_prep, dim3((9 * T2_KS * 256 * 4 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)cw.w,
+                           towerW + (size_t)layer * 9 * T2_KS * T2_SLAB, 9, cw.cout_pad);
+        (void)hipMemcpyAsync(towerB + (size_t)layer * 256, cw.b, (size_t)std::min(cw.cout_pad, 256) * 4, hipMemcpyDeviceToDevice, stream);
+      };
+      for (int i = 0; i < nblocks; ++i) { prep(c1[i], 2 * i); prep(c2[i], 2 * i + 1); }
+      prep(vconv, 2 * nblocks);
+      prep(pconv, 2 * nblocks + 1);
+      hipLaunchKernelGGL(k_tower256_prep_stem, dim3((9 * 256 * 4 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)stem.w, stemW);
+      if (hipStreamSynchronize(stream) != hipSuccess) { *err = "k_tower256_prep failed"; return FPC_ENODEVICE; }
+      use_tower256 = true;
+    }
     loaded = true;
     return 0;
   }
@@ -618,7 +639,7 @@ struct NN {
       return launch_conv<DT>(g, M, err);
     };
     int cur = 0;
-    if (use_tower) {
+    if (use_tower || use_tower256) {
       TowerArgs t{};
       t.boards = in_boards; t.leaf_slot = in_leaf_slot; t.leaf_turn = in_leaf_turn; t.board_stride = in_board_stride; t.one16 = one16();
       in_boards = nullptr;
@@ -635,20 +656,25 @@ struct NN {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 7, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
         attr = true;
       }
-      if (mt == 3) hipLaunchKernelGGL((k_tower<DT, 3, false>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);
+      if (use_tower256) {
+        bool &a256 = attr_tower256[DT];
+        if (!a256) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower256<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS); a256 = true; }
+        hipLaunchKernelGGL((k_tower256<DT>), dim3(n), dim3(TW_THREADS), T2_LDS, stream, t);
+      } else if (mt == 3) hipLaunchKernelGGL((k_tower<DT, 3, false>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);
       else if (mt == 5) hipLaunchKernelGGL((k_tower<DT, 5, false>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);
       else if (P != 16) hipLaunchKernelGGL((k_tower<DT, 7, false>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);
       else hipLaunchKernelGGL((k_tower<DT, 7, true>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);   // 14x14: grid pitch == tile height
       const hipError_t le = hipGetLastError();
       if (le != hipSuccess) { *err = std::string("k_tower launch failed: ") + hipGetErrorString(le); return FPC_ENODEVICE; }
     } else if ((rc = conv(stem, in16, 32, nullptr, act[0], F, F, 0))) return rc;
-    for (int i = 0; i < nblocks && !use_tower; ++i) {
+    const bool fused = use_tower || use_tower256;
+    for (int i = 0; i < nblocks && !fused; ++i) {
       const int t1 = (cur + 1) % 3, t2 = (cur + 2) % 3;
       if ((rc = conv(c1[i], act[cur], F, nullptr, act[t1], F, F, 0))) return rc;
       if ((rc = conv(c2[i], act[t1], F, act[cur], act[t2], F, F, 0))) return rc;
       cur = t2;
     }
-    if (!use_tower) {
+    if (!fused) {
       if ((rc = conv(pconv, act[cur], F, nullptr, xfc, Kp, dc.A_ch, 1))) return rc;
       if ((rc = conv(vconv, act[cur], F, nullptr, yv, 32, 24, 0))) return rc;
     }
@@ -667,7 +693,7 @@ struct NN {
       const hipError_t le = hipGetLastError();
       if (le != hipSuccess) { *err = std::string("k_fc launch failed: ") + hipGetErrorString(le); return FPC_ENODEVICE; }
     }
-    if (!use_tower) hipLaunchKernelGGL((k_value_tail<DT>), dim3(n), dim3(64), 0, stream, (const uint16_t *)(yv + (size_t)guard * 32),
+    if (!fused) hipLaunchKernelGGL((k_value_tail<DT>), dim3(n), dim3(64), 0, stream, (const uint16_t *)(yv + (size_t)guard * 32),
                        (const float *)vw, vb, P, dc.R, PP, n, value_out);
     if (hipGetLastError() != hipSuccess) { *err = "k_value_tail launch failed"; return FPC_ENODEVICE; }
     return 0;

@@ -226,7 +226,7 @@ void resolve_marks(fpc_engine *e) {
 
 extern "C" {
 
-int fpc_abi_version(void) { return 4; }
+int fpc_abi_version(void) { return 5; }
 
 const char *fpc_last_error(const fpc_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
@@ -245,11 +245,11 @@ int fpc_move_flat_index(int R, int from, int to) {
   const bool queen = dx == 0 || dy == 0 || ax == ay;
   const bool knight = (ax == 1 && ay == 2) || (ax == 2 && ay == 1);
   if (!queen && !knight) return -1;
-  DevCfg c{R, 0, R * R, 8 * R + 8, (8 * R + 8) * R * R, 0};
+  DevCfg c = make_devcfg(R, 0, 0);
   return move_plane(c, from, to) * R * R + from;
 }
 int fpc_flat_to_move(int R, int flat, int *from, int *to) {
-  DevCfg c{R, 0, R * R, 8 * R + 8, (8 * R + 8) * R * R, 0};
+  DevCfg c = make_devcfg(R, 0, 0);
   if (flat < 0 || flat >= c.A) return FPC_EINVAL;
   *to = flat_to(c, flat, from);
   return 0;
@@ -318,7 +318,7 @@ int fpc_create(const fpc_config *cfg, fpc_engine **out) {
   fpc_engine *e = new fpc_engine();
   e->cfg = *cfg;
   if (e->cfg.avg_children <= 0) e->cfg.avg_children = 96;
-  e->dc = DevCfg{R, INV, R * R, 8 * R + 8, (8 * R + 8) * R * R, FPC_RULES_STRICT};
+  e->dc = make_devcfg(R, INV, FPC_RULES_STRICT);
   int r = 0;
   auto bail = [&](int code) { g_create_error = e->err; fpc_destroy(e); return code; };
   if (hipStreamCreate(&e->stream) != hipSuccess) { e->err = "hipStreamCreate failed"; return bail(FPC_ENODEVICE); }
@@ -332,7 +332,8 @@ int fpc_create(const fpc_config *cfg, fpc_engine **out) {
       (r = dalloc(e, &t.parent, nn)) || (r = dalloc(e, &t.child0, nn)) || (r = dalloc(e, &t.nch, nn)) ||
       (r = dalloc(e, &t.bslot, nn)) || (r = dalloc(e, &t.boards, (size_t)Gm * t.board_cap)) ||
       (r = dalloc(e, &t.nnodes, Gm)) || (r = dalloc(e, &t.nboards, Gm)) || (r = dalloc(e, &t.alive, Gm)) ||
-      (r = dalloc(e, &t.sims_done, Gm)) || (r = dalloc(e, &t.err, Gm)) || (r = dalloc(e, &t.leaf_node, Gm)) ||
+      (r = dalloc(e, &t.sims_done, Gm)) || (r = dalloc(e, &t.err, Gm)) || (r = dalloc(e, &t.leaf_node, Gm)) || (r = dalloc(e, &t.leaf_node_nx, Gm)) ||
+      (r = dalloc(e, &t.leaf_slot_nx, Gm)) || (r = dalloc(e, &t.leaf_turn_nx, Gm)) ||
       (r = dalloc(e, &t.leaf_turn, Gm)) || (r = dalloc(e, &t.nlegal, Gm)) ||
       (r = dalloc(e, &t.path, (size_t)Gm * t.path_cap)) || (r = dalloc(e, &t.path_len, Gm)) ||
       (r = dalloc(e, &t.legal, (size_t)Gm * FPC_MAX_MOVES)) || (r = dalloc(e, &t.leaf_slot, Gm)) ||
@@ -462,12 +463,14 @@ static int launch_select(fpc_engine *e) {
   return 0;
 }
 
-int fpc_search_select(fpc_engine *e, int *n_live, const float **enc_dev) {
-  if (!e || !e->searching) return fail(e, FPC_ESTATE, "fpc_search_begin has not been called");
-  USE_DEV(e);
-  if (e->sims_issued + 1 > e->cfg.max_sims) return fail(e, FPC_ECAPACITY, "more than max_sims = %d simulations since fpc_search_begin", e->cfg.max_sims);
-  e->sims_issued += 1;
-  launch_select(e);
+// after a k_expand_select launch the leaves it selected become the current ones
+static void swap_leaf_arrays(fpc_engine *e) {
+  std::swap(e->t.leaf_node, e->t.leaf_node_nx);
+  std::swap(e->t.leaf_slot, e->t.leaf_slot_nx);
+  std::swap(e->t.leaf_turn, e->t.leaf_turn_nx);
+}
+
+static int finish_select(fpc_engine *e, int *n_live, const float **enc_dev) {
   FPC_LAUNCH(k_encode, e->G, 64, e->stream, e->dc, (const fpc_board *)e->t.boards, e->t.board_cap,
              (const int *)e->t.leaf_slot, (const int *)e->t.leaf_turn, e->G, 0, e->d_enc_f32, (uint16_t *)nullptr,
              (uint16_t)0, -1);
@@ -482,6 +485,31 @@ int fpc_search_select(fpc_engine *e, int *n_live, const float **enc_dev) {
   if (n_live) *n_live = live;
   if (enc_dev) *enc_dev = e->d_enc_f32;
   return 0;
+}
+
+int fpc_search_select(fpc_engine *e, int *n_live, const float **enc_dev) {
+  if (!e || !e->searching) return fail(e, FPC_ESTATE, "fpc_search_begin has not been called");
+  USE_DEV(e);
+  if (e->sims_issued + 1 > e->cfg.max_sims) return fail(e, FPC_ECAPACITY, "more than max_sims = %d simulations since fpc_search_begin", e->cfg.max_sims);
+  e->sims_issued += 1;
+  launch_select(e);
+  return finish_select(e, n_live, enc_dev);
+}
+
+int fpc_search_expand_select(fpc_engine *e, const float *logits_dev, const float *value_dev, int *n_live, const float **enc_dev) {
+  if (!e || !e->searching) return fail(e, FPC_ESTATE, "fpc_search_begin has not been called");
+  USE_DEV(e);
+  if (!logits_dev || !value_dev) return fail(e, FPC_EINVAL, "null logits/value");
+  if (e->sims_issued + 1 > e->cfg.max_sims) return fail(e, FPC_ECAPACITY, "more than max_sims = %d simulations since fpc_search_begin", e->cfg.max_sims);
+  e->sims_issued += 1;
+  mark(e, 3);
+  FPC_LAUNCH(k_expand_select, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, logits_dev, value_dev, e->Cpuct, (const double *)e->d_logtab);
+  HIPCHK(e, hipGetLastError());
+  swap_leaf_arrays(e);
+  mark(e, 4);
+  e->stats.launches_expand++;
+  mark(e, 0);
+  return finish_select(e, n_live, enc_dev);
 }
 
 int fpc_search_expand(fpc_engine *e, const float *logits_dev, const float *value_dev) {
@@ -506,8 +534,10 @@ int fpc_search_run(fpc_engine *e, int sims) {
   return fail(e, FPC_EWEIGHTS, "the internal ResNet exists only in the gfx950 build");
 #else
   if (!e->nn.loaded) return fail(e, FPC_EWEIGHTS, "fpc_load_weights has not been called");
+  // step s: [k_select] -> network -> k_expand; for all but the last step of this call the expansion and the
+  // NEXT step's selection are one launch (k_expand_select), so a step is 4 dependent kernels instead of 5
   for (int s = 0; s < sims; ++s) {
-    launch_select(e);
+    if (s == 0) launch_select(e); else mark(e, 0);
     if (e->nn.takes_boards())      // the tower megakernel encodes its games' leaves itself
       e->nn.set_board_input((const fpc_board *)e->t.boards, e->t.board_cap, (const int *)e->t.leaf_slot, (const int *)e->t.leaf_turn);
     else
@@ -521,10 +551,21 @@ int fpc_search_run(fpc_engine *e, int sims) {
     e->nn.mark_fn = nullptr;
     if (r) return r;
     mark(e, 3);
-    if (e->policy_mode == FPC_POLICY_LEGAL)
-      FPC_LAUNCH(k_expand_legal, e->G, 64, e->stream, e->dc, e->t, e->G, (const float *)e->nn.legal_logits(), (const float *)e->nn.value());
-    else
-      FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (const float *)e->nn.logits(), (const float *)e->nn.value());
+    const bool fuse = s + 1 < sims;
+    if (e->policy_mode == FPC_POLICY_LEGAL) {
+      if (fuse)
+        FPC_LAUNCH(k_expand_legal_select, e->G, 64, e->stream, e->dc, e->t, e->G, (const float *)e->nn.legal_logits(), (const float *)e->nn.value(),
+                   e->Cpuct, (const double *)e->d_logtab);
+      else
+        FPC_LAUNCH(k_expand_legal, e->G, 64, e->stream, e->dc, e->t, e->G, (const float *)e->nn.legal_logits(), (const float *)e->nn.value());
+    } else {
+      if (fuse)
+        FPC_LAUNCH(k_expand_select, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (const float *)e->nn.logits(), (const float *)e->nn.value(),
+                   e->Cpuct, (const double *)e->d_logtab);
+      else
+        FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (const float *)e->nn.logits(), (const float *)e->nn.value());
+    }
+    if (fuse) swap_leaf_arrays(e);
     mark(e, 4);
     e->stats.launches_select++; e->stats.launches_nn++; e->stats.launches_expand++;
   }

@@ -25,7 +25,13 @@ enum { PAWN = 0, KNIGHT = 1, BISHOP = 2, ROOK = 3, QUEEN = 4, KING = 5 };
 struct DevCfg {
   int R, INV, RR, A_ch, A;
   int rules;         // FPC_RULES_* bits (include/fpc_engine.h); 0 = strict reference semantics
+  int rcpR;          // 65536 / R + 1: q / R == (q * rcpR) >> 16 exactly for 0 <= q < 4681 (R <= 14)
 };
+__host__ __device__ __forceinline__ DevCfg make_devcfg(int R, int INV, int rules) {
+  return DevCfg{R, INV, R * R, 8 * R + 8, (8 * R + 8) * R * R, rules, 65536 / R + 1};
+}
+// square index -> row (the integer division by the runtime board size costs ~40 VALU instructions)
+__host__ __device__ __forceinline__ int row_of(const DevCfg &c, int q) { return (q * c.rcpR) >> 16; }
 
 // error bits accumulated per game / per board (host maps them to fpc_status)
 enum { ERR_SELECT = 1, ERR_POLICY = 2, ERR_CAP_MOVES = 4, ERR_CAP_NODES = 8, ERR_MOVE = 16, ERR_CAP_BOARDS = 32 };
@@ -47,6 +53,8 @@ struct Tree {
   int *leaf_node;    // leaf chosen this step (-1: none)
   int *leaf_slot;    // board-pool slot of that leaf's state (-1: none) -- what k_encode reads
   int *leaf_turn;
+  int *leaf_node_nx, *leaf_slot_nx, *leaf_turn_nx;   // the same three for the NEXT step (k_expand_select writes them while
+                                                     // other games' expansions still read this step's; the host swaps)
   int *nlegal;
   uint16_t *legal;   // [G][FPC_MAX_MOVES] ascending unique flat indices of the leaf's legal moves
   int *path;         // [G][path_cap] root..leaf node ids of this step's descent (k_select -> k_expand's backup)
@@ -58,24 +66,33 @@ struct Tree {
 };
 
 // ---- LDS image of one wave --------------------------------------------------------------------
+constexpr int GEN_SCR = 14;             // per generator slot: a ray has at most 13 targets; slot 7 of a king: 1 step + 2 castlings
 struct __attribute__((aligned(16))) WaveLds {
   fpc_board b;                         // 288 B
+  // pseudo-legal moves in the reference's generation order.  mw packs what the later phases read:
+  //   bits 0-7 to, 8-15 captured piece byte, 17 promotion (the reference emits 4 variants), 20-23 the
+  //   mover's piece-list position (generation order key), 24-31 castling: the rook's square (it hops to
+  //   from + (to-from)/2), else FPC_NO_SQ
+  uint32_t mw[FPC_MAX_MOVES];
   uint8_t mfrom[FPC_MAX_MOVES];
-  uint8_t mto[FPC_MAX_MOVES];
-  uint8_t mcap[FPC_MAX_MOVES];
-  uint8_t mflag[FPC_MAX_MOVES];        // bit0 legal, bit1 promotion (reference emits 4 variants)
-  uint8_t mpiece[FPC_MAX_MOVES];       // piece-list position of the mover (generation order key)
-  uint8_t mrook[FPC_MAX_MOVES];        // castling: the rook's square (it hops to from + (to-from)/2), else FPC_NO_SQ
   uint16_t lflat[FPC_MAX_MOVES];       // flat index of legal moves, reference order
   uint16_t lsorted[FPC_MAX_MOVES];     // ascending
   uint8_t lidx[FPC_MAX_MOVES];         // pseudo-move index of k-th legal move
   float pri[FPC_MAX_MOVES];
+  uint32_t scr[64][2][GEN_SCR];        // generation scratch: lane x generator slot x targets (same packing as mw)
   uint16_t poff[FPC_MAX_PL + 1];       // first pseudo-move of each piece-list entry
   uint8_t l1pos[FPC_MAX_PL];           // own list: position after the GetGameResult reordering
   uint8_t newlist[3][FPC_MAX_PL];      // reordered lists (own, enemy a, enemy b) before they are copied back
+  uint8_t ent[200];                    // square -> 16*list + entry for the three lists a move can touch, else 0xFF
+  int lk[2][48];                       // last move touching each list entry (GetGameResult's loop, GetLegalMoves' loop)
   int M, nlegal, first_legal, result, errbits;
   float scal_f;                        // wave-uniform scalar broadcast slot
 };
+__device__ __forceinline__ int mv_to(uint32_t w) { return (int)(w & 255u); }
+__device__ __forceinline__ uint8_t mv_cap(uint32_t w) { return (uint8_t)(w >> 8); }
+__device__ __forceinline__ int mv_promo(uint32_t w) { return (int)((w >> 17) & 1u); }
+__device__ __forceinline__ int mv_piece(uint32_t w) { return (int)((w >> 20) & 15u); }
+__device__ __forceinline__ int mv_rook(uint32_t w) { return (int)(w >> 24); }
 
 __device__ __forceinline__ bool present(uint8_t p) { return (p & 0x80) != 0; }
 __device__ __forceinline__ int colour_of(uint8_t p) { return (p >> 5) & 3; }
@@ -97,7 +114,8 @@ __host__ __device__ __forceinline__ bool in_array(const DevCfg &c, int row, int 
 
 // move.cpp:13-20, :84-104: (from,to) -> action plane
 __host__ __device__ __forceinline__ int move_plane(const DevCfg &c, int from, int to) {
-  const int dy = to / c.R - from / c.R, dx = to % c.R - from % c.R;
+  const int fr = row_of(c, from), tr = row_of(c, to);
+  const int dy = tr - fr, dx = (to - tr * c.R) - (from - fr * c.R);
   const int ay = dy < 0 ? -dy : dy, ax = dx < 0 ? -dx : dx;
   if (dx == 0 || dy == 0 || ax == ay) {
     const int sx = (dx > 0) - (dx < 0), sy = (dy > 0) - (dy < 0);
@@ -174,51 +192,71 @@ __device__ __forceinline__ void lds_store_board(const WaveLds *s, fpc_board *g) 
   if (l < 8) dst[64 + l] = src[64 + l];
 }
 
-// piece-list primitive used by every reordering: erase the entry for `sq`, append it at the end
-// (== RemovePiece + SetPiece, engine/board.cpp:977-1014, as executed by a make/undo pair)
-__device__ __forceinline__ void list_move_to_end(uint8_t *list, int len, int sq) {
-  int i = 0;
-  while (i < len && list[i] != sq) ++i;
-  if (i >= len) return;
-  for (; i + 1 < len; ++i) list[i] = list[i + 1];
-  list[len - 1] = (uint8_t)sq;
+__device__ __forceinline__ bool promotes(const DevCfg &c, int colour, int tr, int tc) {   // engine/board.cpp:58-76
+  switch (colour) {
+    case 0: return tr == c.R / 4;
+    case 1: return tc == 3 * c.R / 4;
+    case 2: return tr == 3 * c.R / 4;
+    default: return tc == c.R / 4;
+  }
+}
+
+// Piece-list primitive of RemovePiece / SetPiece (engine/board.cpp:977-1014), wave-cooperative: lanes
+// 0..15 hold one entry each, the first entry equal to `sq` is erased (the tail closes up) and `add` (>= 0)
+// is appended.  Returns the new length; *found tells whether `sq` was there.  All lanes must call.
+__device__ __forceinline__ int wave_list_erase_append(uint8_t *list, int len, int sq, int add, bool *found) {
+  const int lane = lane_id();
+  const int v = (lane < len && lane < FPC_MAX_PL) ? list[lane] : -1;
+  const int nxt = __shfl(v, lane + 1 < 64 ? lane + 1 : lane);
+  const unsigned long long hit = __ballot(v == sq);
+  __syncthreads();                                   // every entry is in a register before any is rewritten
+  const int idx = hit ? (int)__ffsll((long long)hit) - 1 : -1;
+  int n = len;
+  if (idx >= 0) {
+    if (lane >= idx && lane + 1 < len) list[lane] = (uint8_t)nxt;
+    n = len - 1;
+  }
+  if (add >= 0 && n < FPC_MAX_PL) { if (lane == 0) list[n] = (uint8_t)add; ++n; }
+  *found = idx >= 0;
+  __syncthreads();
+  return n;
 }
 
 // MakeMove for a tree/self-play move, which carries only (from,to): capture whatever stands on
 // `to`, no promotion, no rook hop, no rights update (engine/board.cpp:1028-1096 with a
-// Move(flat)/Move(plane,from) argument).  Executed by lane 0.  false: "piece missing".
+// Move(flat)/Move(plane,from) argument).  false: "piece missing".
 // With FPC_RULES_FULL_MOVES (the non-strict rule set) the move is executed the way the
 // reference's own generator describes it (engine/board.cpp:58-88, :256-302, :313-466): a pawn that
 // reaches its promotion line becomes a queen, a two-square king move hops the rook, king moves clear the
 // mover's castling rights and a rook leaving its home square clears that side's.
-__device__ __forceinline__ bool make_move_lane0(fpc_board *b, int from, int to, const DevCfg &c) {
+// Wave-cooperative and wave-uniform: every lane derives the same scalars from the LDS board, the piece
+// lists are edited one entry per lane, lane 0 writes the scalars.  All lanes must call.
+__device__ inline bool make_move_wave(fpc_board *b, int from, int to, const DevCfg &c) {
+  const int lane = lane_id();
   if (to == FPC_NO_SQ) return false;
   uint8_t piece = b->sq[from];
   const uint8_t cap = b->sq[to];
+  bool found;
+  __syncthreads();
   if (present(cap)) {  // RemovePiece(to)
     const int cc = colour_of(cap);
-    uint8_t *l = b->pl[cc];
-    int n = b->plen[cc], i = 0;
-    while (i < n && l[i] != to) ++i;
-    if (i < n) { for (; i + 1 < n; ++i) l[i] = l[i + 1]; b->plen[cc] = (uint8_t)(n - 1); }
-    b->sq[to] = 0;
-    if (type_of(cap) == KING) b->king[cc] = FPC_NO_SQ;
+    const int n = wave_list_erase_append(b->pl[cc], b->plen[cc], to, -1, &found);
+    if (lane == 0) {
+      b->plen[cc] = (uint8_t)n;
+      b->sq[to] = 0;
+      if (type_of(cap) == KING) b->king[cc] = FPC_NO_SQ;
+    }
+    __syncthreads();
   }
   if (!present(piece)) return false;
   const int pc = colour_of(piece);
   int rook_from = FPC_NO_SQ, rook_to = FPC_NO_SQ;
+  uint8_t rights = b->castle[pc];
   if (c.rules & FPC_RULES_FULL_MOVES) {
-    const int R = c.R, fr = from / R, fc = from % R, tr = to / R, tc = to % R;
+    const int R = c.R, fr = row_of(c, from), fc = from - fr * R, tr = row_of(c, to), tc = to - tr * R;
     const int ty = type_of(piece);
     if (ty == PAWN) {
-      bool promo;
-      switch (pc) {
-        case 0: promo = tr == R / 4; break;
-        case 1: promo = tc == 3 * R / 4; break;
-        case 2: promo = tr == 3 * R / 4; break;
-        default: promo = tc == R / 4; break;
-      }
-      if (promo) piece = (uint8_t)(0x80 | (pc << 5) | (QUEEN << 2));
+      if (promotes(c, pc, tr, tc)) piece = (uint8_t)(0x80 | (pc << 5) | (QUEEN << 2));
     } else if (ty == KING) {
       const int dr = tr - fr, dc = tc - fc;
       if ((dr == 0 && (dc == 2 || dc == -2)) || (dc == 0 && (dr == 2 || dr == -2))) {   // castling: the rook hops next to the king
@@ -233,8 +271,8 @@ __device__ __forceinline__ bool make_move_lane0(fpc_board *b, int from, int to, 
           }
         }
       }
-      b->castle[pc] = 0;
-    } else if (ty == ROOK && b->castle[pc]) {
+      rights = 0;
+    } else if (ty == ROOK && rights) {
       int ks, qs;      // rook home squares, engine/board.cpp:256-289
       switch (pc) {
         case 0: ks = (R - 1) * R + (R - 4); qs = (R - 1) * R + c.INV; break;
@@ -242,213 +280,201 @@ __device__ __forceinline__ bool make_move_lane0(fpc_board *b, int from, int to, 
         case 2: ks = c.INV; qs = R - 4; break;
         default: ks = c.INV * R + (R - 1); qs = (R - 4) * R + (R - 1); break;
       }
-      if (from == ks) b->castle[pc] &= (uint8_t)~1u;
-      if (from == qs) b->castle[pc] &= (uint8_t)~2u;
+      if (from == ks) rights &= (uint8_t)~1u;
+      if (from == qs) rights &= (uint8_t)~2u;
     }
   }
-  {  // RemovePiece(from) + SetPiece(to, piece)
-    uint8_t *l = b->pl[pc];
-    int n = b->plen[pc], i = 0;
-    while (i < n && l[i] != from) ++i;
-    if (i < n) { for (; i + 1 < n; ++i) l[i] = l[i + 1]; n--; }
-    if (n < FPC_MAX_PL) l[n++] = (uint8_t)to;
+  const uint8_t rook_piece = rook_from != FPC_NO_SQ ? b->sq[rook_from] : (uint8_t)0;
+  // RemovePiece(from) + SetPiece(to, piece)
+  int n = wave_list_erase_append(b->pl[pc], b->plen[pc], from, to, &found);
+  if (rook_from != FPC_NO_SQ) {   // RemovePiece(rook_from) + SetPiece(rook_to): the rook's entry follows the king's
+    const int n2 = wave_list_erase_append(b->pl[pc], n, rook_from, rook_to, &found);
+    if (!found) { if (lane == 0 && n > 0) b->pl[pc][n - 1] = (uint8_t)rook_to; } else n = n2;
+  }
+  if (lane == 0) {
     b->plen[pc] = (uint8_t)n;
     b->sq[from] = 0;
     b->sq[to] = piece;
     if (type_of(piece) == KING) b->king[pc] = (uint8_t)to;
+    if (c.rules & FPC_RULES_FULL_MOVES) b->castle[pc] = rights;
+    if (rook_from != FPC_NO_SQ) { b->sq[rook_to] = rook_piece; b->sq[rook_from] = 0; }
+    b->turn = (uint8_t)((b->turn + 1) & 3);  // GetNextPlayer, engine/board.cpp:1299-1313
   }
-  if (rook_from != FPC_NO_SQ) {   // RemovePiece(rook_from) + SetPiece(rook_to): the rook's entry follows the king's
-    list_move_to_end(b->pl[pc], b->plen[pc], rook_from);
-    b->pl[pc][b->plen[pc] - 1] = (uint8_t)rook_to;
-    b->sq[rook_to] = b->sq[rook_from];
-    b->sq[rook_from] = 0;
-  }
-  b->turn = (uint8_t)((b->turn + 1) & 3);  // GetNextPlayer, engine/board.cpp:1299-1313
+  __syncthreads();
   return true;
 }
 
 // IsAttackedByTeam(team, ksq) on the position obtained from `b` by moving the piece on `from` to
 // `to` -- and, for castling, the rook on `from2` to `to2` -- (virtual make; FPC_NO_SQ squares -> the
 // position itself).  engine/board.cpp:606-787.
+// The function has no side effects, so the reference's probe ORDER is not observable; what costs time
+// on a single wave is the LDS round trip of every dependent probe (~100 cycles each).  All 20 leaper
+// probes (8 knight, 4 pawn, 8 king squares) and the first ATT_PRE squares of the 8 rays are therefore
+// loaded back to back (out-of-range probes read the king's own square and are ignored), evaluated from
+// registers, and only a ray still open after ATT_PRE empty squares continues with dependent loads.
+constexpr int ATT_PRE = 3;
 __device__ inline bool attacked_virtual(const fpc_board *b, const DevCfg &c, int from, int to, uint8_t mover,
                                         int from2, int to2, uint8_t mover2, int ksq, int team) {
   const int R = c.R;
-  const int kr = ksq / R, kc = ksq % R;
-#define FPC_VSQ(q) (((q) == from || (q) == from2) ? (uint8_t)0 : ((q) == to ? mover : ((q) == to2 ? mover2 : b->sq[(q)])))
-  // rooks & queens: rays end at the ARRAY edge, not at the cut corners (:632)
-  for (int d = 0; d < 4; ++d) {
-    const int ri = d == 0 ? -1 : d == 1 ? 1 : 0, ci = d == 2 ? -1 : d == 3 ? 1 : 0;
-    int r = kr + ri, cc = kc + ci;
-    while (in_array(c, r, cc)) {
-      const int q = r * R + cc;
-      const uint8_t p = FPC_VSQ(q);
-      if (present(p)) {
-        if (team_of(p) == team && (type_of(p) == ROOK || type_of(p) == QUEEN)) return true;
-        break;
-      }
-      r += ri; cc += ci;
-    }
-  }
-  // bishops & queens: bounded by IsLegalLocation (:658)
-  for (int d = 0; d < 4; ++d) {
-    const int ri = (d & 2) ? 1 : -1, ci = (d & 1) ? 1 : -1;
-    int r = kr + ri, cc = kc + ci;
-    while (legal_loc(c, r, cc)) {
-      const int q = r * R + cc;
-      const uint8_t p = FPC_VSQ(q);
-      if (present(p)) {
-        if (team_of(p) == team && (type_of(p) == BISHOP || type_of(p) == QUEEN)) return true;
-        break;
-      }
-      r += ri; cc += ci;
-    }
-  }
+  const int kr = row_of(c, ksq), kc = ksq - kr * R;
+#define FPC_VSQ(q, raw) (((q) == from || (q) == from2) ? (uint8_t)0 : ((q) == to ? mover : ((q) == to2 ? mover2 : (raw))))
+  // a piece byte is 1 c c t t t 0 0 (present, colour, type): present + team + type in one masked compare
+  const uint8_t tkey = (uint8_t)(0x80 | (team << 5));
+  int lq[20];
+  uint8_t lraw[20];
   // knights: all 8 offsets regardless of board size (:676-694)
+#pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int dr = (k & 4) ? ((k & 2) ? 1 : -1) : ((k & 2) ? 2 : -2);
     const int dc = (k & 4) ? ((k & 1) ? 2 : -2) : ((k & 1) ? 1 : -1);
     const int r = kr + dr, cc = kc + dc;
-    if (legal_loc(c, r, cc)) {
-      const int q = r * R + cc;
-      const uint8_t p = FPC_VSQ(q);
-      if (present(p) && team_of(p) == team && type_of(p) == KNIGHT) return true;
-    }
+    lq[k] = legal_loc(c, r, cc) ? r * R + cc : -1;
   }
   // pawns (:697-750): array bounds only
+#pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int pr = k >> 1, pc = k & 1;
-    const int r = pr ? kr + 1 : kr - 1, cc = pc ? kc + 1 : kc - 1;
-    if (in_array(c, r, cc)) {
-      const int q = r * R + cc;
-      const uint8_t p = FPC_VSQ(q);
-      if (present(p) && team_of(p) == team && type_of(p) == PAWN) {
-        const int col = colour_of(p);
-        const bool att = col == 0 ? pr != 0 : col == 1 ? pc == 0 : col == 2 ? pr == 0 : pc != 0;
-        if (att) return true;
-      }
-    }
+    const int r = (k >> 1) ? kr + 1 : kr - 1, cc = (k & 1) ? kc + 1 : kc - 1;
+    lq[8 + k] = in_array(c, r, cc) ? r * R + cc : -1;
   }
   // kings (:753-772)
-  for (int k = 0; k < 9; ++k) {
-    if (k == 4) continue;
-    const int r = kr + k / 3 - 1, cc = kc + k % 3 - 1;
-    if (legal_loc(c, r, cc)) {
-      const int q = r * R + cc;
-      const uint8_t p = FPC_VSQ(q);
-      if (present(p) && team_of(p) == team && type_of(p) == KING) return true;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int kk = k < 4 ? k : k + 1;
+    const int r = kr + kk / 3 - 1, cc = kc + kk % 3 - 1;
+    lq[12 + k] = legal_loc(c, r, cc) ? r * R + cc : -1;
+  }
+  // rays: rooks & queens end at the ARRAY edge, not at the cut corners (:632);
+  // bishops & queens are bounded by IsLegalLocation (:658)
+  int rq[8][ATT_PRE];
+  uint8_t rraw[8][ATT_PRE];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    const int ri = d < 4 ? (d == 0 ? -1 : d == 1 ? 1 : 0) : ((d & 2) ? 1 : -1);
+    const int ci = d < 4 ? (d == 2 ? -1 : d == 3 ? 1 : 0) : ((d & 1) ? 1 : -1);
+#pragma unroll
+    for (int k = 0; k < ATT_PRE; ++k) {
+      const int r = kr + ri * (k + 1), cc = kc + ci * (k + 1);
+      const bool in = d < 4 ? in_array(c, r, cc) : legal_loc(c, r, cc);
+      rq[d][k] = in ? r * R + cc : -1;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 20; ++k) lraw[k] = b->sq[lq[k] < 0 ? ksq : lq[k]];
+#pragma unroll
+  for (int d = 0; d < 8; ++d)
+#pragma unroll
+    for (int k = 0; k < ATT_PRE; ++k) rraw[d][k] = b->sq[rq[d][k] < 0 ? ksq : rq[d][k]];
+  bool hit = false;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint8_t p = FPC_VSQ(lq[k], lraw[k]);
+    hit |= lq[k] >= 0 && (p & 0xBC) == (tkey | (KNIGHT << 2));
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint8_t p = FPC_VSQ(lq[8 + k], lraw[8 + k]);
+    const int pr = k >> 1, pc = k & 1, col = colour_of(p);
+    const bool att = col == 0 ? pr != 0 : col == 1 ? pc == 0 : col == 2 ? pr == 0 : pc != 0;
+    hit |= lq[8 + k] >= 0 && (p & 0xBC) == (tkey | (PAWN << 2)) && att;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint8_t p = FPC_VSQ(lq[12 + k], lraw[12 + k]);
+    hit |= lq[12 + k] >= 0 && (p & 0xBC) == (tkey | (KING << 2));
+  }
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    const int slider = d < 4 ? ROOK : BISHOP;
+    bool open = true;
+#pragma unroll
+    for (int k = 0; k < ATT_PRE; ++k) {
+      if (rq[d][k] < 0) open = false;
+      const uint8_t p = FPC_VSQ(rq[d][k], rraw[d][k]);
+      if (open && present(p)) {
+        hit |= team_of(p) == team && (type_of(p) == slider || type_of(p) == QUEEN);
+        open = false;
+      }
+    }
+    if (open) {   // more than ATT_PRE empty squares in this direction: walk on with dependent loads
+      const int ri = d < 4 ? (d == 0 ? -1 : d == 1 ? 1 : 0) : ((d & 2) ? 1 : -1);
+      const int ci = d < 4 ? (d == 2 ? -1 : d == 3 ? 1 : 0) : ((d & 1) ? 1 : -1);
+      int r = kr + ri * (ATT_PRE + 1), cc = kc + ci * (ATT_PRE + 1);
+      while (d < 4 ? in_array(c, r, cc) : legal_loc(c, r, cc)) {
+        const int q = r * R + cc;
+        const uint8_t p = FPC_VSQ(q, b->sq[q]);
+        if (present(p)) {
+          hit |= team_of(p) == team && (type_of(p) == slider || type_of(p) == QUEEN);
+          break;
+        }
+        r += ri; cc += ci;
+      }
     }
   }
 #undef FPC_VSQ
-  return false;
+  return hit;
 }
 
-// Enumerates, in the reference's generation order, the targets of generator slot `d` (0..7) of the
-// piece standing on `from`:  pawn {fwd1, fwd2, capture-, capture+} (engine/board.cpp:97-177),
-// knight (:179-207, loop bound invalid_area = quirk Q8), bishop (:240-254), rook (:256-302),
-// queen = bishop then rook (:304-311), king 8 steps (:313-341).  emit(to, capture, promo).
-template <class F>
-__device__ inline void walk_slot(const fpc_board *b, const DevCfg &c, int from, int d, F &&emit) {
-  const uint8_t piece = b->sq[from];
-  const int type = type_of(piece), colour = colour_of(piece), team = team_of(piece);
-  const int R = c.R, fr = from / R, fc = from % R;
-  int ir = 0, ic = 0;
-  bool ray = false;
-  switch (type) {
-    case PAWN: {
-      if (d >= 4) return;
-      int dr = 0, dc = 0;
-      bool not_moved;
-      switch (colour) {
-        case 0: dr = -1; not_moved = fr == R - 2; break;
-        case 1: dc = 1; not_moved = fc == 1; break;
-        case 2: dr = 1; not_moved = fr == 1; break;
-        default: dc = -1; not_moved = fc == R - 2; break;
-      }
-      int tr, tc;
-      uint8_t cap = 0;
-      if (d < 2) {
-        tr = fr + dr; tc = fc + dc;
-        if (!legal_loc(c, tr, tc) || present(b->sq[tr * R + tc])) return;
-        if (d == 1) {
-          if (!not_moved) return;
-          tr = fr + 2 * dr; tc = fc + 2 * dc;
-          if (!in_array(c, tr, tc) || present(b->sq[tr * R + tc])) return;  // no legality check on the 2nd square (Q15)
-        }
-      } else {
-        tr = fr + dr; tc = fc + dc;
-        const int s = d == 2 ? -1 : 1;
-        if (team == 0) tc += s; else tr += s;
-        if (!legal_loc(c, tr, tc)) return;
-        cap = b->sq[tr * R + tc];
-        if (!present(cap) || team_of(cap) == team) return;
-      }
-      bool promo;  // engine/board.cpp:58-76
-      switch (colour) {
-        case 0: promo = tr == R / 4; break;
-        case 1: promo = tc == 3 * R / 4; break;
-        case 2: promo = tr == 3 * R / 4; break;
-        default: promo = tc == R / 4; break;
-      }
-      emit(tr * R + tc, cap, promo);
-      return;
+// Generator slot `d` (0..7) of a piece, as data: a start square, a step and what a target square may
+// hold.  The reference's generators -- pawn {fwd1, fwd2, capture-, capture+} (engine/board.cpp:97-177),
+// knight (:179-207, loop bound invalid_area = quirk Q8), bishop (:240-254), rook (:256-302), queen =
+// bishop then rook (:304-311), king 8 steps (:313-341) -- all reduce to "step (ir,ic) up to n times".
+enum { GEN_QUIET = 1, GEN_CAPT = 2, GEN_PUSH2 = 4, GEN_PAWN = 8 };
+struct GenSlot {
+  int ir, ic;   // step
+  int n;        // steps left (0: the slot is finished / does not exist)
+  int mode;     // GEN_QUIET: empty targets are moves; GEN_CAPT: an enemy-occupied target is a move;
+                // GEN_PUSH2: pawn double step (the 1st square must be a legal, empty location and is not a
+                // move; the 2nd is only checked against the array bounds, Q15); GEN_PAWN: promotion line
+};
+__device__ __forceinline__ GenSlot gen_slot(const DevCfg &c, int type, int colour, int fr, int fc, int d) {
+  GenSlot g{0, 0, 0, 0};
+  const int R = c.R;
+  if (type == PAWN) {
+    if (d >= 4) return g;
+    int dr = 0, dc = 0;
+    bool not_moved;
+    switch (colour) {
+      case 0: dr = -1; not_moved = fr == R - 2; break;
+      case 1: dc = 1; not_moved = fc == 1; break;
+      case 2: dr = 1; not_moved = fr == 1; break;
+      default: dc = -1; not_moved = fc == R - 2; break;
     }
-    case KNIGHT: {
-      const int per = 2 * (c.INV - 1);
-      if (d >= 2 * per) return;
-      const int prs = d / per, rem = d % per, adr = 1 + rem / 2, pcs = rem & 1;
-      const int dr = prs ? adr : -adr, adc = adr == 1 ? 2 : 1, dc = pcs ? adc : -adc;
-      const int tr = fr + dr, tc = fc + dc;
-      if (!legal_loc(c, tr, tc)) return;
-      const uint8_t cap = b->sq[tr * R + tc];
-      if (present(cap) && team_of(cap) == team) return;
-      emit(tr * R + tc, cap, false);
-      return;
+    g.ir = dr; g.ic = dc;
+    if (d == 0) { g.n = 1; g.mode = GEN_QUIET | GEN_PAWN; }
+    else if (d == 1) { if (not_moved) { g.n = 2; g.mode = GEN_QUIET | GEN_PUSH2 | GEN_PAWN; } }
+    else {
+      const int sd = d == 2 ? -1 : 1;
+      if ((colour & 1) == 0) g.ic += sd; else g.ir += sd;
+      g.n = 1; g.mode = GEN_CAPT | GEN_PAWN;
     }
-    case BISHOP:
-      if (d >= 4) return;
-      ir = (d & 2) ? 1 : -1; ic = (d & 1) ? 1 : -1; ray = true;
-      break;
-    case ROOK:
-    case QUEEN: {
+  } else if (type == KNIGHT) {
+    const int per = 2 * (c.INV - 1);           // 0, 2 or 4 (invalid_area 1..3)
+    if (d >= 2 * per) return g;
+    const int sh = per == 4 ? 2 : 1;
+    const int prs = d >> sh, rem = d & (per - 1), adr = 1 + (rem >> 1), pcs = rem & 1;
+    const int adc = adr == 1 ? 2 : 1;
+    g.ir = prs ? adr : -adr; g.ic = pcs ? adc : -adc;
+    g.n = 1; g.mode = GEN_QUIET | GEN_CAPT;
+  } else if (type == KING) {
+    const int k = d < 4 ? d : d + 1;
+    g.ir = k / 3 - 1; g.ic = k % 3 - 1;
+    g.n = 1; g.mode = GEN_QUIET | GEN_CAPT;
+  } else if (type == BISHOP || type == ROOK || type == QUEEN) {   // AddMovesFromIncrMovement2, engine/board.cpp:209-238
+    const bool diag = type == BISHOP || (type == QUEEN && d < 4);
+    const int rd = type == QUEEN ? d - 4 : d;
+    if (diag) {
+      if (d >= 4) return g;
+      g.ir = (d & 2) ? 1 : -1; g.ic = (d & 1) ? 1 : -1;
+    } else {
       // rook generator order (:291-301): (0,-1), (-1,0), (0,+1), (+1,0)
-      int rd = d;
-      if (type == QUEEN) {
-        if (d < 4) { ir = (d & 2) ? 1 : -1; ic = (d & 1) ? 1 : -1; ray = true; break; }
-        rd = d - 4;
-      }
-      if (rd >= 4) return;
+      if (rd < 0 || rd >= 4) return g;
       const int incr = (rd & 2) ? 1 : -1;
-      if (rd & 1) { ir = incr; ic = 0; } else { ir = 0; ic = incr; }
-      ray = true;
-      break;
+      if (rd & 1) { g.ir = incr; g.ic = 0; } else { g.ir = 0; g.ic = incr; }
     }
-    case KING: {
-      const int k = d < 4 ? d : d + 1;
-      const int tr = fr + k / 3 - 1, tc = fc + k % 3 - 1;
-      if (!legal_loc(c, tr, tc)) return;
-      const uint8_t cap = b->sq[tr * R + tc];
-      if (present(cap) && team_of(cap) == team) return;
-      emit(tr * R + tc, cap, false);
-      return;
-    }
-    default:
-      return;
+    g.n = R; g.mode = GEN_QUIET | GEN_CAPT;
   }
-  if (ray) {  // AddMovesFromIncrMovement2, engine/board.cpp:209-238
-    int tr = fr + ir, tc = fc + ic;
-    while (legal_loc(c, tr, tc)) {
-      const uint8_t cap = b->sq[tr * R + tc];
-      if (!present(cap)) {
-        emit(tr * R + tc, (uint8_t)0, false);
-      } else {
-        if (team_of(cap) != team) emit(tr * R + tc, cap, false);
-        break;
-      }
-      tr += ir; tc += ic;
-    }
-  }
+  return g;
 }
-
 // Castling (engine/board.cpp:343-465), generated after the king's eight steps, queenside first:
 // rights bit set, a same-team rook on the expected square, empty squares between, and neither the
 // king's square nor the first square it crosses attacked.  emit(to, rook_from).  The move travels as
@@ -501,15 +527,48 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
   const bool gen = b->king[turn] != FPC_NO_SQ;   // GetPseudoLegalMoves2 returns 0 without own king (:852-856)
   const bool player_has_king = b->king[player] != FPC_NO_SQ;
 
-  // ---- pass 1: count the moves of this lane's two generator slots (piece p, directions d0,d0+1)
+  // ---- generation, one walk: lane = (piece p, generator slots d0, d0+1).  Both slots advance in the same
+  //      loop (two independent LDS round trips per iteration) and park their targets in the lane's scratch
+  //      rows; the wave scan of the counts then gives every lane its place in the reference's generation order.
   const int p = lane >> 2, d0 = (lane & 3) * 2;
   int cnt0 = 0, cnt1 = 0;
   int from = FPC_NO_SQ;
+  uint32_t *scr0 = s->scr[lane][0], *scr1 = s->scr[lane][1];
   if (gen && p < nown) {
     from = b->pl[turn][p];
-    walk_slot(b, c, from, d0, [&](int, uint8_t, bool) { ++cnt0; });
-    walk_slot(b, c, from, d0 + 1, [&](int, uint8_t, bool) { ++cnt1; });
-    if (d0 == 6 && type_of(b->sq[from]) == KING) walk_castle(b, c, from, [&](int, int) { ++cnt1; });
+    const uint8_t piece = b->sq[from];
+    const int type = type_of(piece), colour = colour_of(piece), team = team_of(piece);
+    const int R = c.R, fr = row_of(c, from), fc = from - fr * R;
+    GenSlot g0 = gen_slot(c, type, colour, fr, fc, d0), g1 = gen_slot(c, type, colour, fr, fc, d0 + 1);
+    int r0 = fr, c0 = fc, r1 = fr, c1 = fc;
+    auto step = [&](GenSlot &g, int &tr, int &tc, uint32_t *scr, int &cnt) {
+      if (g.n <= 0) return;
+      tr += g.ir; tc += g.ic;
+      const bool second = (g.mode & GEN_PUSH2) && g.n == 1;
+      if (!(second ? in_array(c, tr, tc) : legal_loc(c, tr, tc))) { g.n = 0; return; }
+      const int to = tr * R + tc;
+      const uint8_t cap = b->sq[to];
+      bool emit;
+      if (!present(cap)) {
+        emit = (g.mode & GEN_QUIET) && !((g.mode & GEN_PUSH2) && g.n == 2);
+        g.n = (g.mode & GEN_QUIET) ? g.n - 1 : 0;
+      } else {
+        emit = (g.mode & GEN_CAPT) && team_of(cap) != team;
+        g.n = 0;
+      }
+      if (emit && cnt < GEN_SCR) {
+        const bool promo = (g.mode & GEN_PAWN) && promotes(c, colour, tr, tc);
+        scr[cnt++] = (uint32_t)to | ((uint32_t)cap << 8) | (promo ? 1u << 17 : 0u) | ((uint32_t)FPC_NO_SQ << 24);
+      }
+    };
+    while (g0.n > 0 || g1.n > 0) {
+      step(g0, r0, c0, scr0, cnt0);
+      step(g1, r1, c1, scr1, cnt1);
+    }
+    if (d0 == 6 && type == KING)
+      walk_castle(b, c, from, [&](int to, int rook_from) {
+        if (cnt1 < GEN_SCR) scr1[cnt1++] = (uint32_t)to | ((uint32_t)rook_from << 24);
+      });
   }
   // exclusive wave scan of (cnt0+cnt1) in lane order == reference generation order
   int incl = cnt0 + cnt1;
@@ -518,7 +577,7 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
     if (lane >= off) incl += v;
   }
   const int total = __shfl(incl, 63);
-  int base = incl - (cnt0 + cnt1);
+  const int base = incl - (cnt0 + cnt1);
   if ((lane & 3) == 0 && p <= FPC_MAX_PL - 1) s->poff[p] = (uint16_t)(base < FPC_MAX_MOVES ? base : FPC_MAX_MOVES);
   if (lane == 0) {
     s->poff[FPC_MAX_PL] = (uint16_t)(total < FPC_MAX_MOVES ? total : FPC_MAX_MOVES);
@@ -526,24 +585,17 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
     if (nown > FPC_MAX_PL) s->errbits |= ERR_CAP_MOVES;
   }
   const int M = total < FPC_MAX_MOVES ? total : FPC_MAX_MOVES;
-  // ---- pass 2: write them
-  if (from != FPC_NO_SQ) {
-    int w = base;
-    auto put = [&](int to, uint8_t cap, bool promo) {
-      if (w < FPC_MAX_MOVES) {
-        s->mfrom[w] = (uint8_t)from; s->mto[w] = (uint8_t)to; s->mcap[w] = cap; s->mflag[w] = promo ? 2 : 0;
-        s->mpiece[w] = (uint8_t)p; s->mrook[w] = FPC_NO_SQ;
-      }
-      ++w;
-    };
-    walk_slot(b, c, from, d0, put);
-    walk_slot(b, c, from, d0 + 1, put);
-    if (d0 == 6 && type_of(b->sq[from]) == KING)
-      walk_castle(b, c, from, [&](int to, int rook_from) {
-        put(to, (uint8_t)0, false);
-        if (w - 1 < FPC_MAX_MOVES) s->mrook[w - 1] = (uint8_t)rook_from;
-      });
+  {  // scratch rows -> the dense move list
+    const uint32_t tag = (uint32_t)p << 20;
+    const int kmax = cnt0 > cnt1 ? cnt0 : cnt1;
+    for (int k = 0; k < kmax; ++k) {
+      if (k < cnt0 && base + k < FPC_MAX_MOVES) { s->mw[base + k] = scr0[k] | tag; s->mfrom[base + k] = (uint8_t)from; }
+      if (k < cnt1 && base + cnt0 + k < FPC_MAX_MOVES) { s->mw[base + cnt0 + k] = scr1[k] | tag; s->mfrom[base + cnt0 + k] = (uint8_t)from; }
+    }
   }
+  // square -> list entry map and the "last move touching this entry" slots of the reordering below
+  if (lane < 50) reinterpret_cast<uint32_t *>(s->ent)[lane] = 0xFFFFFFFFu;
+  if (lane < 48) { s->lk[0][lane] = -1; s->lk[1][lane] = -1; }
   __syncthreads();
 
   // ---- legality: lane i tests move i on the virtual post-move board (IsKingSafeAfterMove, board.cpp:59-68)
@@ -552,22 +604,23 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
   for (int base_i = 0; base_i < M; base_i += 64) {
     const int i = base_i + lane;
     bool legal = false;
+    int f = 0, t = 0;
     if (i < M) {
-      const int f = s->mfrom[i], t = s->mto[i];
+      const uint32_t w = s->mw[i];
+      f = s->mfrom[i]; t = mv_to(w);
       const uint8_t mover = b->sq[f];
       int ksq = b->king[player];
       if (type_of(mover) == KING && colour_of(mover) == player) ksq = t;
       else if (ksq == t) ksq = FPC_NO_SQ;               // the player's king itself was captured
-      const int rf = s->mrook[i];                       // castling: the rook hops next to the king
+      const int rf = mv_rook(w);                        // castling: the rook hops next to the king
       const int rt = rf == FPC_NO_SQ ? FPC_NO_SQ : f + (t - f) / 2;
       legal = ksq == FPC_NO_SQ ? true : !attacked_virtual(b, c, f, t, mover, rf, rt, rf == FPC_NO_SQ ? (uint8_t)0 : b->sq[rf], ksq, enemy);
-      if (legal) s->mflag[i] |= 1;
     }
     const unsigned long long bal = __ballot(legal);
     if (legal) {
       const int k = nlegal + __popcll(bal & ((1ull << lane) - 1ull));
       s->lidx[k] = (uint8_t)i;
-      s->lflat[k] = (uint16_t)(move_plane(c, s->mfrom[i], s->mto[i]) * c.RR + s->mfrom[i]);
+      s->lflat[k] = (uint16_t)(move_plane(c, f, t) * c.RR + f);
     }
     if (first < 0 && bal) first = base_i + (int)__ffsll((long long)bal) - 1;
     nlegal += __popcll(bal);
@@ -580,7 +633,7 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
     if (!player_has_king) {
       result = team_of_colour(player) == 0 ? FPC_WIN_BG : FPC_WIN_RY;
     } else if (nlegal > 0) {
-      const uint8_t cap = s->mcap[first];                // only the FIRST legal move is inspected (Q13)
+      const uint8_t cap = mv_cap(s->mw[first]);          // only the FIRST legal move is inspected (Q13)
       if (present(cap) && type_of(cap) == KING) result = team_of(cap) == 0 ? FPC_WIN_BG : FPC_WIN_RY;
     } else {
       const bool chk = attacked_virtual(b, c, FPC_NO_SQ, FPC_NO_SQ, 0, FPC_NO_SQ, FPC_NO_SQ, 0, b->king[player], enemy);
@@ -614,15 +667,28 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
       }
       return rank;
     };
-    // GetGameResult's loop: key = move index
-    int lk1 = -1;
-    if (phase1 && my_lane) {
-      for (int i = 0; i <= upto; ++i) {
-        const bool rook_hit = grp == 0 && s->mrook[i] == mysq;   // the rook is re-appended AFTER the king
-        const bool hit = grp == 0 ? (s->mpiece[i] == e || rook_hit) : (present(s->mcap[i]) && s->mto[i] == mysq);
-        if (hit) lk1 = 2 * i + (rook_hit ? 1 : 0);
+    // Which entry a move touches is looked up through the square -> entry map, and every move posts its
+    // key to the entries it touches with an LDS atomic max (keys grow along the loop, so the maximum is
+    // the LAST move touching the entry): one step per move instead of every entry scanning all moves.
+    if (my_lane) s->ent[mysq] = (uint8_t)lane;
+    __syncthreads();
+    auto post = [&](int *lk, int i, uint32_t w, int key) {
+      atomicMax(&lk[mv_piece(w)], key);                          // the mover
+      const int rook = mv_rook(w);
+      if (rook != FPC_NO_SQ) {                                   // the rook is re-appended AFTER the king
+        const int en = s->ent[rook];
+        if (en < 16) atomicMax(&lk[en], key + 1);
       }
-    }
+      if (present(mv_cap(w))) {                                  // the captured piece (always an enemy entry)
+        const int en = s->ent[mv_to(w)];
+        if (en >= 16 && en < 48) atomicMax(&lk[en], key);
+      }
+    };
+    // GetGameResult's loop: key = move index
+    if (phase1)
+      for (int i = lane; i <= upto; i += 64) post(s->lk[0], i, s->mw[i], 2 * i);
+    __syncthreads();
+    const int lk1 = (phase1 && my_lane) ? s->lk[0][lane] : -1;
     const bool t1 = my_lane && lk1 >= 0;
     const unsigned long long T1 = __ballot(t1), L = __ballot(my_lane);
     const int r1 = rank_in_group(lk1, t1);
@@ -631,18 +697,14 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
     if (grp == 0 && my_lane) s->l1pos[e] = (uint8_t)(phase1 ? pos1 : e);
     __syncthreads();
     // GetLegalMoves' loop: key = (post-GetGameResult position of the mover, its per-piece move index)
-    int lk2 = -1;
-    if (run_legal && my_lane) {
-      for (int i = 0; i < M; ++i) {
-        const bool rook_hit = grp == 0 && s->mrook[i] == mysq;
-        const bool hit = grp == 0 ? (s->mpiece[i] == e || rook_hit) : (present(s->mcap[i]) && s->mto[i] == mysq);
-        if (hit) {
-          const int pc = s->mpiece[i];
-          const int key = 2 * ((int)s->l1pos[pc] * 256 + (i - (int)s->poff[pc])) + (rook_hit ? 1 : 0);
-          lk2 = key > lk2 ? key : lk2;
-        }
+    if (run_legal)
+      for (int i = lane; i < M; i += 64) {
+        const uint32_t w = s->mw[i];
+        const int pc = mv_piece(w);
+        post(s->lk[1], i, w, 2 * ((int)s->l1pos[pc] * 256 + (i - (int)s->poff[pc])));
       }
-    }
+    __syncthreads();
+    const int lk2 = (run_legal && my_lane) ? s->lk[1][lane] : -1;
     const bool t2 = my_lane && lk2 >= 0;
     const unsigned long long T2 = __ballot(t2);
     const int r2 = rank_in_group(lk2, t2);
@@ -684,13 +746,9 @@ __global__ void __launch_bounds__(64) k_board_ops(DevCfg c, fpc_board *boards, i
   lds_load_board(&s, &boards[g]);
   int e = 0;
   if (ops & OP_TAKE) {
-    if (lane == 0) {
-      int from;
-      const int to = flat_to(c, flat[g], &from);
-      s.errbits = make_move_lane0(&s.b, from, to, c) ? 0 : ERR_MOVE;
-    }
-    __syncthreads();
-    e |= s.errbits;
+    int from;
+    const int to = flat_to(c, flat[g], &from);
+    if (!make_move_wave(&s.b, from, to, c)) e |= ERR_MOVE;
   }
   if (ops & (OP_LEGAL | OP_RESULT)) {
     wave_position_ops(&s, c, (ops & OP_RESULT) != 0, (ops & OP_LEGAL) != 0, player ? player[g] : -1);
@@ -702,7 +760,8 @@ __global__ void __launch_bounds__(64) k_board_ops(DevCfg c, fpc_board *boards, i
       for (int k = lane; k < nl; k += 64) {
         const int i = s.lidx[k];
         fpc_move m;
-        m.from = s.mfrom[i]; m.to = s.mto[i]; m.capture = s.mcap[i]; m.promo = (s.mflag[i] >> 1) & 1;
+        const uint32_t w = s.mw[i];
+        m.from = s.mfrom[i]; m.to = (uint8_t)mv_to(w); m.capture = mv_cap(w); m.promo = (uint8_t)mv_promo(w);
         m.flat = s.lflat[k]; m.pad = 0;
         moves[(size_t)g * FPC_MAX_MOVES + k] = m;
       }
@@ -888,40 +947,47 @@ __device__ __forceinline__ void backprop_path(const Tree &t, size_t nb, int g, f
   }
 }
 
-__global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double Cpuct, const double *logtab) {
-  __shared__ WaveLds s;
-  const int g = blockIdx.x;
-  if (g >= G) return;
+// One game's selection step, executed by one wave (all 64 lanes call; `s` is the wave's LDS image).
+// The chosen leaf goes to leaf_node/leaf_slot/leaf_turn, or to their _nx twins when `to_next`.
+__device__ inline void select_game(WaveLds &s, const DevCfg &c, const Tree &t, int g, double Cpuct, const double *logtab, bool to_next) {
   const int lane = lane_id();
+  int *const leaf_node = to_next ? t.leaf_node_nx : t.leaf_node;
+  int *const leaf_slot = to_next ? t.leaf_slot_nx : t.leaf_slot;
+  int *const leaf_turn = to_next ? t.leaf_turn_nx : t.leaf_turn;
   if (!t.alive[g]) {                        // root already removed from the search (Q5)
-    if (lane == 0) { t.leaf_node[g] = -1; t.leaf_slot[g] = -1; }
+    if (lane == 0) { leaf_node[g] = -1; leaf_slot[g] = -1; }
     return;
   }
   const size_t nb = (size_t)g * t.node_cap;
   // ---- descent: SelectChild (node.cpp:49-78)
   //   ucb_i = W_i/N_i + C * sqrt( log(sqrt(N_parent)) / (1 + N_i) ) * P_i      (fp64, no contraction)
   //   strict '>' from -inf => lowest index wins ties, NaN never wins
+  // Every level costs ONE dependent global round trip: the lanes that fetch the children's N/W/P also
+  // fetch each child's (first child, child count), so the chosen child's own children can be requested
+  // as soon as the argmax is known.
   int n = 0, depth = 0;
   bool fail = false;
   int *path = t.path + (size_t)g * t.path_cap;
+  int c0 = t.child0[nb], nc = t.nch[nb], Nn = t.N[nb];
   for (;;) {
     if (lane == 0 && depth < t.path_cap) path[depth] = n;
     ++depth;
-    const int c0 = t.child0[nb + n];
     if (c0 < 0) break;
-    const int nc = t.nch[nb + n];
-    const double L = logtab[t.N[nb + n]];
-    const double sqrtNp = sqrt((double)t.N[nb + n]);
+    const double L = logtab[Nn];
+    const double sqrtNp = sqrt((double)Nn);
     double best = 0.0;
-    int besti = -1;
+    int besti = -1, best_c0 = -1, best_nc = 0, best_N = 0;
     for (int base = 0; base < nc; base += 64) {
       const int i = base + lane;
       double u = 0.0;
       bool valid = false;
+      int Nc = 0, cc0 = -1, cnc = 0;
       if (i < nc) {
-        const int Nc = t.N[nb + c0 + i];
+        Nc = t.N[nb + c0 + i];
         const double Wc = t.W[nb + c0 + i];
         const double Pc = (double)t.P[nb + c0 + i];
+        cc0 = t.child0[nb + c0 + i];
+        cnc = t.nch[nb + c0 + i];
         if (c.rules & FPC_RULES_PUCT) {
           // AlphaZero PUCT, the child's value seen from the parent: -W/N + C P sqrt(N_parent) / (1 + N)
           const double q = Nc > 0 ? -(Wc / (double)Nc) : 0.0;
@@ -940,13 +1006,16 @@ __global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double C
         const int i2 = __shfl_xor(idx, off);
         if (u2 > u || (u2 == u && i2 < idx)) { u = u2; idx = i2; }
       }
-      if (idx != 0x7fffffff && (besti < 0 || u > best)) { best = u; besti = idx; }
+      const int src = idx != 0x7fffffff ? idx - base : 0;
+      const int w_c0 = __shfl(cc0, src), w_nc = __shfl(cnc, src), w_N = __shfl(Nc, src);
+      if (idx != 0x7fffffff && (besti < 0 || u > best)) { best = u; besti = idx; best_c0 = w_c0; best_nc = w_nc; best_N = w_N; }
     }
     if (besti < 0) { fail = true; break; }
     n = c0 + besti;
+    c0 = best_c0; nc = best_nc; Nn = best_N;
   }
   if (fail) {                                // node.cpp:72-75 throws
-    if (lane == 0) { t.err[g] |= ERR_SELECT; t.alive[g] = 0; t.leaf_node[g] = -1; t.leaf_slot[g] = -1; }
+    if (lane == 0) { t.err[g] |= ERR_SELECT; t.alive[g] = 0; leaf_node[g] = -1; leaf_slot[g] = -1; }
     return;
   }
   // ---- leaf state: the reference copies + MakeMoves a Board for every child at expansion time
@@ -956,10 +1025,11 @@ __global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double C
   if (slot < 0) {
     const int par = t.parent[nb + n];
     lds_load_board(&s, &pool[t.bslot[nb + par]]);
+    int from;
+    const int to = flat_to(c, t.mv[nb + n], &from);
+    const bool moved = make_move_wave(&s.b, from, to, c);
     if (lane == 0) {
-      int from;
-      const int to = flat_to(c, t.mv[nb + n], &from);
-      int e = make_move_lane0(&s.b, from, to, c) ? 0 : ERR_MOVE;
+      int e = moved ? 0 : ERR_MOVE;
       int ns = t.nboards[g];
       if (ns >= t.board_cap) { e |= ERR_CAP_BOARDS; ns = -1; } else { t.nboards[g] = ns + 1; t.bslot[nb + n] = ns; }
       s.first_legal = ns;                    // broadcast through LDS
@@ -969,7 +1039,7 @@ __global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double C
     slot = s.first_legal;
     __syncthreads();
     if (slot < 0) {                          // board pool exhausted: the game leaves the search, nothing is overwritten
-      if (lane == 0) { t.alive[g] = 0; t.leaf_node[g] = -1; t.leaf_slot[g] = -1; }
+      if (lane == 0) { t.alive[g] = 0; leaf_node[g] = -1; leaf_slot[g] = -1; }
       return;
     }
   } else {
@@ -986,15 +1056,22 @@ __global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double C
       backprop_lane0(t, nb, n, res == FPC_STALEMATE ? 0.0f : -1.0f);
       t.sims_done[g] += 1;
       t.alive[g] = 0;
-      t.leaf_node[g] = -1;
-      t.leaf_slot[g] = -1;
+      leaf_node[g] = -1;
+      leaf_slot[g] = -1;
     }
     return;
   }
   const int nl = s.nlegal;
   uint16_t *lg = t.legal + (size_t)g * FPC_MAX_MOVES;
   for (int k = lane; k < nl; k += 64) lg[k] = s.lsorted[k];
-  if (lane == 0) { t.leaf_node[g] = n; t.leaf_slot[g] = slot; t.leaf_turn[g] = s.b.turn; t.nlegal[g] = nl; t.path_len[g] = depth; }
+  if (lane == 0) { leaf_node[g] = n; leaf_slot[g] = slot; leaf_turn[g] = s.b.turn; t.nlegal[g] = nl; t.path_len[g] = depth; }
+}
+
+__global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double Cpuct, const double *logtab) {
+  __shared__ WaveLds s;
+  const int g = blockIdx.x;
+  if (g >= G) return;
+  select_game(s, c, t, g, Cpuct, logtab, false);
 }
 
 // ================================================================================================
@@ -1107,12 +1184,10 @@ __device__ __forceinline__ void expand_finish(WaveLds &s, const Tree &t, int g, 
 constexpr int EXPAND_THREADS = 256;   // 4 waves stream the logits row; wave 0 then finishes alone
 constexpr int EXPAND_MAXQ = 23;        // float4 groups per thread: ceil(A / 4 / 256) at A = 23520 (14x14)
 static_assert(EXPAND_MAXQ * EXPAND_THREADS * 4 >= (8 * 14 + 8) * 14 * 14, "k_expand keeps a whole logits row (board <= 14x14) in registers");
-__global__ void __launch_bounds__(EXPAND_THREADS) k_expand(DevCfg c, Tree t, int G, const float *logits, const float *value) {
-  __shared__ WaveLds s;
-  __shared__ float red_f[4];
-  __shared__ int red_i[4];
-  const int g = blockIdx.x;
-  if (g >= G) return;
+// One game's expansion, executed by the EXPAND_THREADS threads of its block (waves 1-3 only help to
+// stream the logits row and return early).
+__device__ inline void expand_game(WaveLds &s, float *red_f, int *red_i, const DevCfg &c, const Tree &t, int G, int g, const float *logits,
+                                   const float *value) {
   const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
   const int n = t.leaf_node[g];
   const int turn0 = (c.rules & FPC_RULES_ROTATION) ? t.leaf_turn[g] : first_leaf_turn(t.leaf_node, t.leaf_turn, G);
@@ -1179,6 +1254,32 @@ __global__ void __launch_bounds__(EXPAND_THREADS) k_expand(DevCfg c, Tree t, int
   expand_finish(s, t, g, nb, n, nl, nan, value);
 }
 
+__global__ void __launch_bounds__(EXPAND_THREADS) k_expand(DevCfg c, Tree t, int G, const float *logits, const float *value) {
+  __shared__ WaveLds s;
+  __shared__ float red_f[4];
+  __shared__ int red_i[4];
+  const int g = blockIdx.x;
+  if (g >= G) return;
+  expand_game(s, red_f, red_i, c, t, G, g, logits, value);
+}
+
+// k_expand of simulation step s followed, for the same game, by k_select of step s+1 (one launch and one
+// dependent-kernel gap less per step).  Other blocks may still be expanding step s when this block's
+// selection publishes its leaf, and strict mode reads the turn of the batch's FIRST live leaf across games
+// (Q6), so the selection writes the _nx leaf arrays; the host swaps them in after the launch.
+__global__ void __launch_bounds__(EXPAND_THREADS) k_expand_select(DevCfg c, Tree t, int G, const float *logits, const float *value,
+                                                                  double Cpuct, const double *logtab) {
+  __shared__ WaveLds s;
+  __shared__ float red_f[4];
+  __shared__ int red_i[4];
+  const int g = blockIdx.x;
+  if (g >= G) return;
+  expand_game(s, red_f, red_i, c, t, G, g, logits, value);
+  if (threadIdx.x >= 64) return;
+  __syncthreads();                           // the new children (global stores of other lanes) are visible to the descent
+  select_game(s, c, t, g, Cpuct, logtab, true);
+}
+
 
 // ================================================================================================
 // k_expand_legal: the same step for the LEGAL-ONLY policy head (opt-in, fpc_set_policy_mode): the
@@ -1190,10 +1291,7 @@ __global__ void __launch_bounds__(EXPAND_THREADS) k_expand(DevCfg c, Tree t, int
 // maximum, which the full softmax would flush to zero (child dropped / policy error) and this form
 // cannot see.  One wave per game.
 // ================================================================================================
-__global__ void __launch_bounds__(64) k_expand_legal(DevCfg c, Tree t, int G, const float *ll, const float *value) {
-  __shared__ WaveLds s;
-  const int g = blockIdx.x;
-  if (g >= G) return;
+__device__ inline void expand_legal_game(WaveLds &s, const DevCfg &c, const Tree &t, int g, const float *ll, const float *value) {
   const int lane = lane_id();
   const int n = t.leaf_node[g];
   if (n < 0) return;
@@ -1212,6 +1310,24 @@ __global__ void __launch_bounds__(64) k_expand_legal(DevCfg c, Tree t, int G, co
   }
   __syncthreads();
   expand_finish(s, t, g, nb, n, nl, nan, value);
+}
+
+__global__ void __launch_bounds__(64) k_expand_legal(DevCfg c, Tree t, int G, const float *ll, const float *value) {
+  __shared__ WaveLds s;
+  const int g = blockIdx.x;
+  if (g >= G) return;
+  expand_legal_game(s, c, t, g, ll, value);
+}
+
+// the legal-only head's counterpart of k_expand_select
+__global__ void __launch_bounds__(64) k_expand_legal_select(DevCfg c, Tree t, int G, const float *ll, const float *value, double Cpuct,
+                                                            const double *logtab) {
+  __shared__ WaveLds s;
+  const int g = blockIdx.x;
+  if (g >= G) return;
+  expand_legal_game(s, c, t, g, ll, value);
+  __syncthreads();
+  select_game(s, c, t, g, Cpuct, logtab, true);
 }
 
 }  // namespace fpc

@@ -75,6 +75,7 @@ _SIGS = {
     "fpc_search_begin": (C.c_int, [C.c_void_p, P(Board), C.c_int, C.c_double]),
     "fpc_search_select": (C.c_int, [C.c_void_p, P(C.c_int), P(C.c_void_p)]),
     "fpc_search_expand": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fpc_search_expand_select": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int), P(C.c_void_p)]),
     "fpc_search_run": (C.c_int, [C.c_void_p, C.c_int]),
     "fpc_search_results": (C.c_int, [C.c_void_p, P(Board), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -252,6 +253,13 @@ class Engine:
 
     def search_expand(self, logits_ptr, value_ptr):
         self._chk(self.L.fpc_search_expand(self.h, logits_ptr, value_ptr))
+
+    def search_expand_select(self, logits_ptr, value_ptr):
+        """search_expand of this simulation + search_select of the next one in one launch."""
+        n = C.c_int()
+        p = C.c_void_p()
+        self._chk(self.L.fpc_search_expand_select(self.h, logits_ptr, value_ptr, C.byref(n), C.byref(p)))
+        return n.value, p.value
 
     def search_run(self, sims):
         self._chk(self.L.fpc_search_run(self.h, sims))

@@ -115,9 +115,14 @@ class MCTS:
         host_engine = not torch.cuda.is_available()    # only true for the test-suite's emulator build
         R, A = eng.R, eng.A
         keep = None
-        for _ in range(sims):
-            n_live, enc_ptr = eng.search_select()
+        # mcts.py:36-38: select -> evaluate -> expand per simulation; between two evaluations the expansion and the
+        # next selection are one launch (fpc_search_expand_select)
+        n_live, enc_ptr = eng.search_select() if sims > 0 else (0, None)
+        for i in range(sims):
+            last = i == sims - 1
             if n_live == 0:
+                if not last:
+                    n_live, enc_ptr = eng.search_select()
                 continue
             if host_engine:
                 import ctypes
@@ -134,7 +139,10 @@ class MCTS:
                 value = value.to(device="cuda", dtype=torch.float32).contiguous().view(G)
                 torch.cuda.synchronize()
             keep = (logits, value)
-            eng.search_expand(logits.data_ptr(), value.data_ptr())
+            if last:
+                eng.search_expand(logits.data_ptr(), value.data_ptr())
+            else:
+                n_live, enc_ptr = eng.search_expand_select(logits.data_ptr(), value.data_ptr())
             if not host_engine:
                 torch.cuda.synchronize()
         del keep

@@ -136,6 +136,10 @@ int fpc_search_select(fpc_engine *e, int *n_live, const float **enc_dev);
 /* softmax/ParseActionspace/mask/renormalise + BackpropagateNodes + ExpandNodes (mcts.py:67-89).
  * logits_dev [n_games, A] f32 and value_dev [n_games] f32 are DEVICE pointers (slot g = game g). */
 int fpc_search_expand(fpc_engine *e, const float *logits_dev, const float *value_dev);
+/* fpc_search_expand of this simulation followed by fpc_search_select of the next one, as ONE launch
+ * (k_expand_select): what the loop mcts.py:36-38 does between two evaluator calls.  Same arguments and
+ * results as the two calls it replaces; use plain fpc_search_expand after the last evaluation. */
+int fpc_search_expand_select(fpc_engine *e, const float *logits_dev, const float *value_dev, int *n_live, const float **enc_dev);
 /* all `sims` simulations with the internal network (weights from fpc_load_weights) */
 int fpc_search_run(fpc_engine *e, int sims);
 /* How fpc_search_run evaluates the policy head (net.py:22-26 + mcts.py:67-76):

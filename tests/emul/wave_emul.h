@@ -131,6 +131,8 @@ inline T __shfl_up(T v, int delta) {
   const int l = wemu::st().cur % wemu::WAVE;
   return wemu::exchange(v, l - delta >= 0 ? l - delta : l);
 }
+// LDS atomics: fibres are cooperative (one runs at a time), so a plain read-modify-write is atomic
+inline int atomicMax(int *p, int v) { const int o = *p; if (v > o) *p = v; return o; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 

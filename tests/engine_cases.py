@@ -134,8 +134,9 @@ def case_search_golden(backend, R, max_sims, kinds=None, max_cases=None):
         ev = evaluators.make(rec["kind"], R)
         roots = [fpc_ffi.board_from_lists(R, s["turn"], s["pl"]) for s in rec["before"]]
         eng = make_engine(backend, R, INV, max_games=len(roots), max_sims=rec["sims"])
-        res = run_external_search(eng, backend, roots, rec["sims"], rec["C"], ev)
-        tag = (si, rec["kind"], rec["sims"])
+        # every other case drives the loop through the fused fpc_search_expand_select entry point
+        res = run_external_search(eng, backend, roots, rec["sims"], rec["C"], ev, fused=bool(done & 1))
+        tag = (si, rec["kind"], rec["sims"], "fused" if done & 1 else "stepwise")
         for gi, ref in enumerate(rec["roots"]):
             n = int(res["n_children"][gi])
             got = [[int(res["flat"][gi, k]), int(res["visits"][gi, k])] for k in range(n)]
@@ -454,7 +455,7 @@ def case_fixed_rules_vs_oracle(backend, R, n_games=6, plies=60, sims=40, seed=31
             for c in range(4):
                 fb.castle[c] = b.castle[c]
             roots.append(fb)
-        res = run_external_search(eng, backend, roots, sims, 3.0, ev)
+        res = run_external_search(eng, backend, roots, sims, 3.0, ev, fused=True)
         _compare_search(res, oref, ("fixed", R, rules))
         if noise:      # the noise really entered: strict-rule priors differ
             eng.set_root_noise(None, 0.0)

@@ -51,15 +51,19 @@ class DevPtr:
                                          "version": 2}
 
 
-def run_external_search(eng, backend, roots, sims, c_puct, evaluator):
+def run_external_search(eng, backend, roots, sims, c_puct, evaluator, fused=False):
     """Drives fpc_search_select / evaluator / fpc_search_expand exactly like mcts.py:36-38 does.
-    evaluator: numpy callable(enc[G,24,R,R]) -> (logits[G,A], value[G])."""
+    evaluator: numpy callable(enc[G,24,R,R]) -> (logits[G,A], value[G]).
+    fused: between two evaluations use fpc_search_expand_select (one launch) instead of expand + select."""
     G, R, A = len(roots), eng.R, eng.A
     eng.search_begin(roots, c_puct)
     keep = []
-    for _ in range(sims):
-        n_live, enc_ptr = eng.search_select()
+    n_live, enc_ptr = eng.search_select() if sims > 0 else (0, None)
+    for i in range(sims):
+        last = i == sims - 1
         if n_live == 0:
+            if not last:
+                n_live, enc_ptr = eng.search_select()
             continue
         if backend == "emul":
             enc = np.ctypeslib.as_array(C.cast(enc_ptr, C.POINTER(C.c_float)), shape=(G, 24, R, R))
@@ -67,7 +71,7 @@ def run_external_search(eng, backend, roots, sims, c_puct, evaluator):
             lg = np.ascontiguousarray(lg, dtype=np.float32)
             v = np.ascontiguousarray(v, dtype=np.float32)
             keep = [lg, v]
-            eng.search_expand(lg.ctypes.data, v.ctypes.data)
+            lp, vp = lg.ctypes.data, v.ctypes.data
         else:
             import torch
             enc_t = torch.as_tensor(DevPtr(enc_ptr, (G, 24, R, R)), device="cuda")
@@ -77,7 +81,15 @@ def run_external_search(eng, backend, roots, sims, c_puct, evaluator):
             v_t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda()
             torch.cuda.synchronize()
             keep = [lg_t, v_t]
-            eng.search_expand(lg_t.data_ptr(), v_t.data_ptr())
+            lp, vp = lg_t.data_ptr(), v_t.data_ptr()
+        if fused and not last:
+            n_live, enc_ptr = eng.search_expand_select(lp, vp)
+        else:
+            eng.search_expand(lp, vp)
+            if not last:
+                n_live, enc_ptr = eng.search_select()
+        if backend != "emul":
+            import torch
             torch.cuda.synchronize()
     del keep
     return eng.search_results(roots=roots)

@@ -100,16 +100,17 @@ __device__ __forceinline__ int type_of(uint8_t p) { return (p >> 2) & 7; }
 __device__ __forceinline__ int team_of_colour(int c) { return c & 1; }   // RED/YELLOW 0, BLUE/GREEN 1 (engine/board.h:64-67)
 __device__ __forceinline__ int team_of(uint8_t p) { return (p >> 5) & 1; }
 
-// engine/board.h:647-654
+// engine/board.h:647-654.  Branch-free on purpose (bitwise & |): these run per lane in divergent code, where
+// every short-circuit turns into an exec-mask save/restore and a branch.
 __device__ __forceinline__ bool legal_loc(const DevCfg &c, int row, int col) {
   const int mx = c.R - 1;
-  if (row < 0 || row > mx || col < 0 || col > mx) return false;
-  const bool cc = col < c.INV || col > mx - c.INV;
-  if (cc && (row < c.INV || row > mx - c.INV)) return false;
-  return true;
+  const bool in = ((unsigned)row <= (unsigned)mx) & ((unsigned)col <= (unsigned)mx);
+  const bool cc = (col < c.INV) | (col > mx - c.INV);
+  const bool rr = (row < c.INV) | (row > mx - c.INV);
+  return in & !(cc & rr);
 }
 __host__ __device__ __forceinline__ bool in_array(const DevCfg &c, int row, int col) {
-  return row >= 0 && row < c.R && col >= 0 && col < c.R;
+  return ((unsigned)row < (unsigned)c.R) & ((unsigned)col < (unsigned)c.R);
 }
 
 // move.cpp:13-20, :84-104: (from,to) -> action plane
@@ -313,11 +314,19 @@ __device__ inline bool make_move_wave(fpc_board *b, int from, int to, const DevC
 // loaded back to back (out-of-range probes read the king's own square and are ignored), evaluated from
 // registers, and only a ray still open after ATT_PRE empty squares continues with dependent loads.
 constexpr int ATT_PRE = 3;
-__device__ inline bool attacked_virtual(const fpc_board *b, const DevCfg &c, int from, int to, uint8_t mover,
+__device__ __attribute__((noinline)) bool attacked_virtual(const fpc_board *b, const DevCfg &c, int from, int to, uint8_t mover,
                                         int from2, int to2, uint8_t mover2, int ksq, int team) {
   const int R = c.R;
   const int kr = row_of(c, ksq), kc = ksq - kr * R;
-#define FPC_VSQ(q, raw) (((q) == from || (q) == from2) ? (uint8_t)0 : ((q) == to ? mover : ((q) == to2 ? mover2 : (raw))))
+  // content of square q after the virtual move: a chain of plain selects (lowest priority first), no branches
+  auto vsq = [&](int q, uint32_t raw) -> uint8_t {
+    uint32_t v = raw;
+    v = q == to2 ? (uint32_t)mover2 : v;
+    v = q == to ? (uint32_t)mover : v;
+    v = ((q == from) | (q == from2)) ? 0u : v;
+    return (uint8_t)v;
+  };
+#define FPC_VSQ(q, raw) vsq((q), (raw))
   // a piece byte is 1 c c t t t 0 0 (present, colour, type): present + team + type in one masked compare
   const uint8_t tkey = (uint8_t)(0x80 | (team << 5));
   int lq[20];
@@ -368,34 +377,39 @@ __device__ inline bool attacked_virtual(const fpc_board *b, const DevCfg &c, int
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const uint8_t p = FPC_VSQ(lq[k], lraw[k]);
-    hit |= lq[k] >= 0 && (p & 0xBC) == (tkey | (KNIGHT << 2));
+    hit |= (lq[k] >= 0) & ((p & 0xBC) == (tkey | (KNIGHT << 2)));
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint8_t p = FPC_VSQ(lq[8 + k], lraw[8 + k]);
+    // the pawn of colour `col` attacks diagonally forward: red (0) upwards, so it sits one row below (pr = 1), ...
     const int pr = k >> 1, pc = k & 1, col = colour_of(p);
-    const bool att = col == 0 ? pr != 0 : col == 1 ? pc == 0 : col == 2 ? pr == 0 : pc != 0;
-    hit |= lq[8 + k] >= 0 && (p & 0xBC) == (tkey | (PAWN << 2)) && att;
+    const bool att = ((col == 0) & (pr != 0)) | ((col == 1) & (pc == 0)) | ((col == 2) & (pr == 0)) | ((col == 3) & (pc != 0));
+    hit |= (lq[8 + k] >= 0) & ((p & 0xBC) == (tkey | (PAWN << 2))) & att;
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const uint8_t p = FPC_VSQ(lq[12 + k], lraw[12 + k]);
-    hit |= lq[12 + k] >= 0 && (p & 0xBC) == (tkey | (KING << 2));
+    hit |= (lq[12 + k] >= 0) & ((p & 0xBC) == (tkey | (KING << 2)));
   }
+  unsigned open_rays = 0;     // bit d: ray d saw ATT_PRE empty in-range squares
 #pragma unroll
   for (int d = 0; d < 8; ++d) {
-    const int slider = d < 4 ? ROOK : BISHOP;
+    const uint8_t slider = (uint8_t)(tkey | ((d < 4 ? ROOK : BISHOP) << 2)), queen = (uint8_t)(tkey | (QUEEN << 2));
     bool open = true;
 #pragma unroll
     for (int k = 0; k < ATT_PRE; ++k) {
-      if (rq[d][k] < 0) open = false;
       const uint8_t p = FPC_VSQ(rq[d][k], rraw[d][k]);
-      if (open && present(p)) {
-        hit |= team_of(p) == team && (type_of(p) == slider || type_of(p) == QUEEN);
-        open = false;
-      }
+      const bool in = rq[d][k] >= 0, occ = present(p);
+      hit |= open & in & (((p & 0xBC) == slider) | ((p & 0xBC) == queen));
+      open = open & in & !occ;
     }
-    if (open) {   // more than ATT_PRE empty squares in this direction: walk on with dependent loads
+    open_rays |= open ? 1u << d : 0u;
+  }
+  if (open_rays && !hit) {   // more than ATT_PRE empty squares in some direction: walk on with dependent loads
+    for (int d = 0; d < 8; ++d) {
+      if (!((open_rays >> d) & 1u)) continue;
+      const int slider = d < 4 ? ROOK : BISHOP;
       const int ri = d < 4 ? (d == 0 ? -1 : d == 1 ? 1 : 0) : ((d & 2) ? 1 : -1);
       const int ci = d < 4 ? (d == 2 ? -1 : d == 3 ? 1 : 0) : ((d & 1) ? 1 : -1);
       int r = kr + ri * (ATT_PRE + 1), cc = kc + ci * (ATT_PRE + 1);

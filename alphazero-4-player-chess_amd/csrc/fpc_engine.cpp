@@ -753,7 +753,7 @@ struct Rccl {
 };
 struct Id128 { char b[128]; };    // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128), passed by value
 
-Rccl &rccl() {
+extern "C++" Rccl &rccl() {
   static Rccl r;
   if (r.h || !r.err.empty()) return r;
   // FPC_RCCL_LIB: the host layer names the copy that belongs to the HIP runtime already in the process

@@ -29,6 +29,8 @@ def make(kind, R):
             logits = u.astype(np.float32) / np.float32(8192.0) - np.float32(4.0)
         elif kind == "hashinf":
             logits = np.where((u % np.uint64(4)) == 0, np.float32(-np.inf), np.float32(0)).astype(np.float32)
+        elif kind == "hashinf1":     # sparse -inf (1 logit in 32) among hash logits: searches that run to the end with -inf in the softmax
+            logits = np.where((u % np.uint64(32)) == 0, np.float32(-np.inf), u.astype(np.float32) / np.float32(8192.0) - np.float32(4.0)).astype(np.float32)
         else:
             raise ValueError(kind)
         v = ((h % np.uint64(9)).astype(np.float32) - 4) / 4

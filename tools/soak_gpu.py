@@ -18,6 +18,9 @@ for seed in range(100, 100 + n):
         print("size", R, seed, "ok", flush=True)
     ec.case_castling_vs_oracle("gpu", n_games=8, plies=60, sims=40, seed=seed)
     print("castling", seed, "ok", flush=True)
+    for R, rules in ((14, 15), (8, 15), (14, 5)):
+        k = ec.case_fixed_rules_vs_oracle("gpu", R, n_games=6, plies=60, sims=40, seed=seed, rules=rules, noise=(seed & 1) == 0)
+        print("fixed-rules", R, rules, seed, k, flush=True)
     for R in (8, 14):
         k = ec.case_arena_vs_oracle("gpu", R, n_pairs=4, sims=40, max_len=40, seed=seed)
         print("arena", R, seed, k, flush=True)

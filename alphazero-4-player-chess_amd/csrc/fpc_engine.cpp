@@ -52,6 +52,7 @@ struct fpc_engine {
   bool searching = false;
   double *d_logtab = nullptr;
   float *d_enc_f32 = nullptr;     // [max_games,24,R,R]
+  float *d_stats = nullptr;       // [max_games][SM_MAXCH][SM_REC] softmax chunk statistics of external logits
   fpc_board *d_roots = nullptr;   // staging [max_games]
   int *d_rc_i = nullptr;          // root-children gather: [2][rc_cap] flat | visits
   float *d_rc_f = nullptr;
@@ -337,7 +338,7 @@ int fpc_create(const fpc_config *cfg, fpc_engine **out) {
       (r = dalloc(e, &t.leaf_turn, Gm)) || (r = dalloc(e, &t.nlegal, Gm)) ||
       (r = dalloc(e, &t.path, (size_t)Gm * t.path_cap)) || (r = dalloc(e, &t.path_len, Gm)) ||
       (r = dalloc(e, &t.legal, (size_t)Gm * FPC_MAX_MOVES)) || (r = dalloc(e, &t.leaf_slot, Gm)) ||
-      (r = dalloc(e, &e->d_enc_f32, (size_t)Gm * 24 * e->dc.RR)) || (r = dalloc(e, &e->d_roots, Gm)) ||
+      (r = dalloc(e, &e->d_enc_f32, (size_t)Gm * 24 * e->dc.RR)) || (r = dalloc(e, &e->d_stats, (size_t)Gm * SM_MAXCH * SM_REC)) || (r = dalloc(e, &e->d_roots, Gm)) ||
       (r = dalloc(e, &e->d_logtab, (size_t)cfg->max_sims + 16)) ||
       (r = dalloc(e, &e->d_rc_meta, (size_t)Gm * 3)))
     return bail(r);
@@ -463,6 +464,12 @@ static int launch_select(fpc_engine *e) {
   return 0;
 }
 
+// softmax chunk statistics of logits that did not come from the internal policy Linear
+static void launch_partials(fpc_engine *e, const float *logits_dev) {
+  const int nchunks = (e->dc.A / 4 + SM_THREADS - 1) / SM_THREADS;
+  FPC_LAUNCH(k_softmax_partials, e->G * nchunks, SM_THREADS, e->stream, logits_dev, e->dc.A, e->G, nchunks, e->d_stats);
+}
+
 // after a k_expand_select launch the leaves it selected become the current ones
 static void swap_leaf_arrays(fpc_engine *e) {
   std::swap(e->t.leaf_node, e->t.leaf_node_nx);
@@ -503,7 +510,9 @@ int fpc_search_expand_select(fpc_engine *e, const float *logits_dev, const float
   if (e->sims_issued + 1 > e->cfg.max_sims) return fail(e, FPC_ECAPACITY, "more than max_sims = %d simulations since fpc_search_begin", e->cfg.max_sims);
   e->sims_issued += 1;
   mark(e, 3);
-  FPC_LAUNCH(k_expand_select, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, logits_dev, value_dev, e->Cpuct, (const double *)e->d_logtab);
+  launch_partials(e, logits_dev);
+  FPC_LAUNCH(k_expand_select, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, logits_dev, (const float *)e->d_stats, value_dev, e->Cpuct,
+             (const double *)e->d_logtab);
   HIPCHK(e, hipGetLastError());
   swap_leaf_arrays(e);
   mark(e, 4);
@@ -517,7 +526,8 @@ int fpc_search_expand(fpc_engine *e, const float *logits_dev, const float *value
   USE_DEV(e);
   if (!logits_dev || !value_dev) return fail(e, FPC_EINVAL, "null logits/value");
   mark(e, 3);
-  FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, logits_dev, value_dev);
+  launch_partials(e, logits_dev);
+  FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, logits_dev, (const float *)e->d_stats, value_dev);
   HIPCHK(e, hipGetLastError());
   mark(e, 4);
   e->stats.launches_expand++;
@@ -560,10 +570,11 @@ int fpc_search_run(fpc_engine *e, int sims) {
         FPC_LAUNCH(k_expand_legal, e->G, 64, e->stream, e->dc, e->t, e->G, (const float *)e->nn.legal_logits(), (const float *)e->nn.value());
     } else {
       if (fuse)
-        FPC_LAUNCH(k_expand_select, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (const float *)e->nn.logits(), (const float *)e->nn.value(),
-                   e->Cpuct, (const double *)e->d_logtab);
+        FPC_LAUNCH(k_expand_select, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (const float *)e->nn.logits(), (const float *)e->nn.stats(),
+                   (const float *)e->nn.value(), e->Cpuct, (const double *)e->d_logtab);
       else
-        FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (const float *)e->nn.logits(), (const float *)e->nn.value());
+        FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (const float *)e->nn.logits(), (const float *)e->nn.stats(),
+                   (const float *)e->nn.value());
     }
     if (fuse) swap_leaf_arrays(e);
     mark(e, 4);

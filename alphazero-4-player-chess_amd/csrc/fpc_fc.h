@@ -205,19 +205,28 @@ __global__ void __launch_bounds__(FC_THREADS, 1) k_fc(FcArgs g) {
 }
 
 // logits[m][n] = bias[n] + slab[base][m][n%256] + slab[base+1][m][n%256] + ...   (fixed order)
+// Sums a column group's K-split slabs and the bias in fixed order, writes the logits, and -- while the
+// block still holds its 1024 logits of the row in registers -- leaves that chunk's softmax statistics
+// (softmax_chunk_stats, fpc_tree_kernels.h) for the expansion, which then never sweeps the row again.
 __global__ void __launch_bounds__(256) k_fc_reduce(const float *part, const float *bias, int G1, int s1, int s2, int Mtot, int A,
-                                                   int n_rows, float *logits) {
+                                                   int n_rows, float *logits, float *stats) {
+  __shared__ float red[8];
   const int q = blockIdx.x * 256 + threadIdx.x;         // float4 index within a row
   const int m = blockIdx.y;
-  if (m >= n_rows || q * 4 >= A) return;
-  const int j = q >> 6;                                 // column group of 256
-  const int base = j < G1 ? j * s1 : G1 * s1 + (j - G1) * s2, cnt = j < G1 ? s1 : s2;
-  float4 v = *reinterpret_cast<const float4 *>(bias + q * 4);
-  for (int k = 0; k < cnt; ++k) {
-    const float4 p = *reinterpret_cast<const float4 *>(part + ((long)(base + k) * Mtot + m) * 256 + (q & 63) * 4);
-    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+  if (m >= n_rows) return;
+  const bool valid = q * 4 < A;
+  float4 v{0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+    const int j = q >> 6;                               // column group of 256
+    const int base = j < G1 ? j * s1 : G1 * s1 + (j - G1) * s2, cnt = j < G1 ? s1 : s2;
+    v = *reinterpret_cast<const float4 *>(bias + q * 4);
+    for (int k = 0; k < cnt; ++k) {
+      const float4 p = *reinterpret_cast<const float4 *>(part + ((long)(base + k) * Mtot + m) * 256 + (q & 63) * 4);
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    *reinterpret_cast<float4 *>(logits + (long)m * A + q * 4) = v;
   }
-  *reinterpret_cast<float4 *>(logits + (long)m * A + q * 4) = v;
+  softmax_chunk_stats(v, valid, red, stats + ((long)m * SM_MAXCH + blockIdx.x) * SM_REC);
 }
 
 }  // namespace fpc

@@ -423,6 +423,7 @@ struct NN {
   uint16_t *yv = nullptr;        // value conv out [guard + Mrows + guard][32] (ld 32)
   uint16_t *xfc = nullptr;       // [Gpad][Kp]
   float *d_logits = nullptr;     // [Gmax][A]
+  float *d_stats = nullptr;      // [Gmax][SM_MAXCH][SM_REC] softmax chunk statistics of d_logits' rows (k_fc_reduce)
   float *d_value = nullptr;      // [Gmax]
   ConvW stem, pconv, vconv;
   std::vector<ConvW> c1, c2;
@@ -473,6 +474,7 @@ struct NN {
   void set_board_input(const fpc_board *b, int stride, const int *slot, const int *turn) { in_boards = b; in_board_stride = stride; in_leaf_slot = slot; in_leaf_turn = turn; }
   uint16_t one16() const { return dtype ? 0x3C00 : 0x3F80; }
   float *logits() { return d_logits; }
+  float *stats() { return d_stats; }
   float *value() { return d_value; }
   uint16_t *fcw2 = nullptr;      // row-major [Np][Kp] copy of the policy weights (legal-only head), made on first use
   float *d_ll = nullptr;         // [Gmax][FPC_MAX_MOVES] logits of the leaves' legal moves
@@ -556,6 +558,7 @@ struct NN {
     if ((rc = dmalloc(&fc_part, (size_t)2 * FC_SPLITK * Gpad * Np, err))) return rc;
     plan_fc();
     if ((rc = dmalloc(&d_logits, (size_t)Gmax * dc.A, err))) return rc;
+    if ((rc = dmalloc(&d_stats, (size_t)Gmax * SM_MAXCH * SM_REC, err))) return rc;
     if ((rc = dmalloc(&d_value, (size_t)Gmax, err))) return rc;
     use_tower = false;
     if (F == 128 && !getenv("FPC_NO_TOWER")) {
@@ -689,7 +692,7 @@ struct NN {
       if (!fattr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fc<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS); fattr = true; }
       hipLaunchKernelGGL((k_fc<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), FC_LDS, stream, f);
       hipLaunchKernelGGL(k_fc_reduce, dim3((dc.A / 4 + 255) / 256, n), dim3(256), 0, stream, (const float *)fc_part, (const float *)fcb,
-                         fc_G1, FC_SPLITK, fc_s2, Gpad, dc.A, n, logits_out);
+                         fc_G1, FC_SPLITK, fc_s2, Gpad, dc.A, n, logits_out, d_stats);
       const hipError_t le = hipGetLastError();
       if (le != hipSuccess) { *err = std::string("k_fc launch failed: ") + hipGetErrorString(le); return FPC_ENODEVICE; }
     }

@@ -1187,76 +1187,90 @@ __device__ __forceinline__ void expand_finish(WaveLds &s, const Tree &t, int g, 
 }
 
 // ================================================================================================
+// Softmax statistics of a logits row, by chunks of 1024 logits (= 256 threads x float4) -- the first half
+// of the numeric spec of mcts.py:67.  Chunk c of a row: m_c = its maximum,
+// s_c = sum of fpc_expf(x - m_c) in the order "thread t owns float4 group t of the chunk, adds x,y,z,w
+// ascending; xor butterfly 32..1 inside each 64-lane wave; ((w0+w1)+w2)+w3", flag = a NaN was seen.
+// The policy Linear's k_fc_reduce produces the records while it still holds the logits in registers
+// (fpc_fc.h); k_softmax_partials produces the same records for logits handed in by an external evaluator.
+// ================================================================================================
+constexpr int SM_THREADS = 256;
+constexpr int SM_REC = 4;              // floats per chunk record: max, sum, NaN flag, pad
+constexpr int SM_MAXCH = 32;           // records per row (A <= 32768; 23 at 14x14)
+// all SM_THREADS threads call; `red`: 8 floats of shared memory
+__device__ __forceinline__ void softmax_chunk_stats(float4 v, bool valid, float *red, float *rec) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float m = -__builtin_inff();
+  bool nan = false;
+  if (valid) {
+    nan = (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+    m = v.x > m ? v.x : m; m = v.y > m ? v.y : m; m = v.z > m ? v.z : m; m = v.w > m ? v.w : m;
+  }
+  for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(m, off); m = o > m ? o : m; }
+  const bool wnan = __ballot(nan) != 0ull;
+  if (lane == 0) { red[wave] = m; red[4 + wave] = wnan ? 1.f : 0.f; }
+  __syncthreads();
+  m = red[0];
+  m = red[1] > m ? red[1] : m; m = red[2] > m ? red[2] : m; m = red[3] > m ? red[3] : m;
+  const float nf = ((red[4] != 0.f) | (red[5] != 0.f) | (red[6] != 0.f) | (red[7] != 0.f)) ? 1.f : 0.f;
+  __syncthreads();
+  float part = 0.f;
+  if (valid && m > -__builtin_inff()) {
+    part = part + fpc_expf(v.x - m);
+    part = part + fpc_expf(v.y - m);
+    part = part + fpc_expf(v.z - m);
+    part = part + fpc_expf(v.w - m);
+  }
+  for (int off = 32; off >= 1; off >>= 1) part = part + __shfl_xor(part, off);
+  if (lane == 0) red[wave] = part;
+  __syncthreads();
+  if (tid == 0) { rec[0] = m; rec[1] = ((red[0] + red[1]) + red[2]) + red[3]; rec[2] = nf; rec[3] = 0.f; }
+}
+
+// grid = G * nchunks blocks: block b -> (row b / nchunks, chunk b % nchunks)
+__global__ void __launch_bounds__(SM_THREADS) k_softmax_partials(const float *logits, int A, int G, int nchunks, float *stats) {
+  __shared__ float red[8];
+  const int g = (int)blockIdx.x / nchunks, ch = (int)blockIdx.x % nchunks;
+  if (g >= G) return;
+  const int q = ch * SM_THREADS + (int)threadIdx.x;
+  const bool valid = q * 4 < A;
+  const float4 v = valid ? *reinterpret_cast<const float4 *>(logits + (size_t)g * A + 4 * q) : float4{0.f, 0.f, 0.f, 0.f};
+  softmax_chunk_stats(v, valid, red, stats + ((size_t)g * SM_MAXCH + ch) * SM_REC);
+}
+
+// ================================================================================================
 // k_expand: mcts.py:67-89 for one leaf per wave.
 //   p = softmax(logits) over all A entries;  policy_abs[pl][r][c] = p[pl][rot90 by -turn0]  (Q6);
 //   prior_j = p_src(j) / sum_legal p  for the ascending legal list; exact zeros get no child;
 //   BackpropagateNodes(value) first (Q4), then children appended with N=1 (Q1), W=0.
-// Summation orders are part of the numeric spec: S = thread partials over float4 groups
-// (group q belongs to thread q%256, ascending) + per-wave xor butterfly + the 4 wave sums in wave
-// order; the legal mass is a sequential ascending f32 sum.
+// Numeric spec, second half: m = max_c m_c; S = sequential ascending sum over the
+// chunks of s_c * fpc_expf(m_c - m) (a chunk of -inf only contributes 0); p_i = fpc_expf(l_i - m) * (1/S);
+// the legal mass is a sequential ascending f32 sum.  The row itself is only touched at the legal moves.
 // ================================================================================================
-constexpr int EXPAND_THREADS = 256;   // 4 waves stream the logits row; wave 0 then finishes alone
-constexpr int EXPAND_MAXQ = 23;        // float4 groups per thread: ceil(A / 4 / 256) at A = 23520 (14x14)
-static_assert(EXPAND_MAXQ * EXPAND_THREADS * 4 >= (8 * 14 + 8) * 14 * 14, "k_expand keeps a whole logits row (board <= 14x14) in registers");
-// One game's expansion, executed by the EXPAND_THREADS threads of its block (waves 1-3 only help to
-// stream the logits row and return early).
-__device__ inline void expand_game(WaveLds &s, float *red_f, int *red_i, const DevCfg &c, const Tree &t, int G, int g, const float *logits,
+constexpr int EXPAND_THREADS = 64;
+__device__ inline void expand_game(WaveLds &s, const DevCfg &c, const Tree &t, int G, int g, const float *logits, const float *stats,
                                    const float *value) {
-  const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+  const int lane = lane_id();
   const int n = t.leaf_node[g];
   const int turn0 = (c.rules & FPC_RULES_ROTATION) ? t.leaf_turn[g] : first_leaf_turn(t.leaf_node, t.leaf_turn, G);
   if (n < 0) return;
   const size_t nb = (size_t)g * t.node_cap;
   const float *lg = logits + (size_t)g * c.A;
-  const int A = c.A, ngroups = A / 4;        // A = (8R+8)*R*R is a multiple of 4 for even R
-  // The row is swept ONCE: every thread pulls all of its float4 groups (q % 256 == tid, at most
-  // EXPAND_MAXQ of them) into registers with the loads back to back -- one memory round trip instead
-  // of one per loop iteration, twice -- and both passes then run from registers.
-  float4 v[EXPAND_MAXQ];
-#pragma unroll
-  for (int i = 0; i < EXPAND_MAXQ; ++i) {
-    const int q = tid + i * EXPAND_THREADS;
-    v[i] = q < ngroups ? *reinterpret_cast<const float4 *>(lg + 4 * q) : float4{0.f, 0.f, 0.f, 0.f};
-  }
-  // pass 1: max
-  float m = -__builtin_inff();
-  bool nan = false;
-#pragma unroll
-  for (int i = 0; i < EXPAND_MAXQ; ++i) {
-    if (tid + i * EXPAND_THREADS < ngroups) {
-      nan |= (v[i].x != v[i].x) | (v[i].y != v[i].y) | (v[i].z != v[i].z) | (v[i].w != v[i].w);
-      m = v[i].x > m ? v[i].x : m; m = v[i].y > m ? v[i].y : m; m = v[i].z > m ? v[i].z : m; m = v[i].w > m ? v[i].w : m;
-    }
-  }
-  for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(m, off); m = o > m ? o : m; }
-  const bool wnan = __ballot(nan) != 0ull;
-  if (lane == 0) { red_f[wave] = m; red_i[wave] = wnan ? 1 : 0; }
-  __syncthreads();
-  m = red_f[0];
-  m = red_f[1] > m ? red_f[1] : m; m = red_f[2] > m ? red_f[2] : m; m = red_f[3] > m ? red_f[3] : m;
-  nan = (red_i[0] | red_i[1] | red_i[2] | red_i[3]) != 0;
-  __syncthreads();
-  // pass 2: S.  Thread t owns the float4 groups q with q % 256 == t (ascending), each wave folds its
-  // 64 partials with the xor butterfly, and the four wave sums are added in wave order.
-  float part = 0.f;
-#pragma unroll
-  for (int i = 0; i < EXPAND_MAXQ; ++i) {
-    if (tid + i * EXPAND_THREADS < ngroups) {
-      part = part + fpc_expf(v[i].x - m);
-      part = part + fpc_expf(v[i].y - m);
-      part = part + fpc_expf(v[i].z - m);
-      part = part + fpc_expf(v[i].w - m);
-    }
-  }
-  for (int off = 32; off >= 1; off >>= 1) part = part + __shfl_xor(part, off);
-  if (lane == 0) red_f[wave] = part;
-  __syncthreads();
-  if (wave != 0) return;                     // the rest is one wave's work (uniform exit of waves 1-3)
-  part = ((red_f[0] + red_f[1]) + red_f[2]) + red_f[3];
-  const float inv = fdiv_rn(1.0f, part);
-  // legal priors
+  const int nchunks = (c.A / 4 + SM_THREADS - 1) / SM_THREADS;     // A = (8R+8)*R*R is a multiple of 4 for even R
+  const float *st = stats + (size_t)g * SM_MAXCH * SM_REC;
+  // the legal logits are requested before the statistics are reduced (independent round trips)
   const int nl = t.nlegal[g];
   const uint16_t *legal = t.legal + (size_t)g * FPC_MAX_MOVES;
+  float mc = -__builtin_inff(), sc = 0.f;
+  bool nan = false;
+  if (lane < nchunks) { mc = st[lane * SM_REC]; sc = st[lane * SM_REC + 1]; nan = st[lane * SM_REC + 2] != 0.f; }
+  float m = mc;
+  for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(m, off); m = o > m ? o : m; }
+  nan = __ballot(nan) != 0ull;
+  const float term = (lane < nchunks && mc > -__builtin_inff()) ? sc * fpc_expf(mc - m) : 0.f;
+  float S = 0.f;
+  for (int k = 0; k < nchunks; ++k) S = S + __shfl(term, k);
+  const float inv = fdiv_rn(1.0f, S);
   for (int j = lane; j < nl; j += 64) {
     const int fl = legal[j];
     const int plane = fl / c.RR, pos = fl % c.RR;
@@ -1268,28 +1282,23 @@ __device__ inline void expand_game(WaveLds &s, float *red_f, int *red_i, const D
   expand_finish(s, t, g, nb, n, nl, nan, value);
 }
 
-__global__ void __launch_bounds__(EXPAND_THREADS) k_expand(DevCfg c, Tree t, int G, const float *logits, const float *value) {
+__global__ void __launch_bounds__(EXPAND_THREADS) k_expand(DevCfg c, Tree t, int G, const float *logits, const float *stats, const float *value) {
   __shared__ WaveLds s;
-  __shared__ float red_f[4];
-  __shared__ int red_i[4];
   const int g = blockIdx.x;
   if (g >= G) return;
-  expand_game(s, red_f, red_i, c, t, G, g, logits, value);
+  expand_game(s, c, t, G, g, logits, stats, value);
 }
 
 // k_expand of simulation step s followed, for the same game, by k_select of step s+1 (one launch and one
 // dependent-kernel gap less per step).  Other blocks may still be expanding step s when this block's
 // selection publishes its leaf, and strict mode reads the turn of the batch's FIRST live leaf across games
 // (Q6), so the selection writes the _nx leaf arrays; the host swaps them in after the launch.
-__global__ void __launch_bounds__(EXPAND_THREADS) k_expand_select(DevCfg c, Tree t, int G, const float *logits, const float *value,
-                                                                  double Cpuct, const double *logtab) {
+__global__ void __launch_bounds__(EXPAND_THREADS) k_expand_select(DevCfg c, Tree t, int G, const float *logits, const float *stats,
+                                                                  const float *value, double Cpuct, const double *logtab) {
   __shared__ WaveLds s;
-  __shared__ float red_f[4];
-  __shared__ int red_i[4];
   const int g = blockIdx.x;
   if (g >= G) return;
-  expand_game(s, red_f, red_i, c, t, G, g, logits, value);
-  if (threadIdx.x >= 64) return;
+  expand_game(s, c, t, G, g, logits, stats, value);
   __syncthreads();                           // the new children (global stores of other lanes) are visible to the descent
   select_game(s, c, t, g, Cpuct, logtab, true);
 }

@@ -653,26 +653,46 @@ float orc_expf(float x) {
   return p * s;
 }
 
-// mcts.py:67-76.  Numeric spec (DESIGN.md "policy head-to-prior arithmetic"):
-//   m = max logits; e_i = fpc_expf(l_i - m); S = thread-ordered sum (thread t of 256 owns the float4
-//   groups g with g % 256 == t, added in ascending order; xor-butterfly 32,16,..,1 inside each of
-//   the four 64-lane waves; then ((w0+w1)+w2)+w3);
-//   p_i = e_i * (1/S); priors = p_src / (sequential ascending sum of p over the legal set).
+// mcts.py:67-76.  Numeric spec ("policy head-to-prior arithmetic"):
+//   the row is taken in chunks of 1024 logits (256 "threads" x float4).  Chunk c: m_c = its maximum;
+//   s_c = sum of fpc_expf(l - m_c) where thread t owns float4 group t of the chunk and adds x,y,z,w in
+//   order, the 64 partials of each of the four "waves" are folded by the xor butterfly 32,16,..,1 and the
+//   wave sums are added ((w0+w1)+w2)+w3 (a chunk that is all -inf has s_c = 0);
+//   m = max_c m_c;  S = sequential ascending sum of s_c * fpc_expf(m_c - m) (chunks with m_c = -inf add 0);
+//   p_i = fpc_expf(l_i - m) * (1/S); priors = p_src / (sequential ascending sum of p over the legal set).
 int orc_policy_priors(const float *logits, int R, int turn0, const int *legal_flat, int n_legal, float *priors) {
   int A = orc_action_size(R), RR = R * R;
-  float m = -std::numeric_limits<float>::infinity();
+  const float NINF = -std::numeric_limits<float>::infinity();
   bool has_nan = false;
-  for (int i = 0; i < A; ++i) { if (logits[i] != logits[i]) has_nan = true; if (logits[i] > m) m = logits[i]; }
-  float part[256];
-  for (int l = 0; l < 256; ++l) part[l] = 0.f;
-  for (int i = 0; i < A; ++i) part[(i / 4) % 256] = part[(i / 4) % 256] + orc_expf(logits[i] - m);
-  for (int w = 0; w < 4; ++w)
-    for (int off = 32; off >= 1; off >>= 1) {
-      float nxt[64];
-      for (int l = 0; l < 64; ++l) nxt[l] = part[w * 64 + l] + part[w * 64 + (l ^ off)];
-      memcpy(part + w * 64, nxt, sizeof(nxt));
+  const int ngroups = A / 4, nchunks = (ngroups + 255) / 256;
+  std::vector<float> mc(nchunks), sc(nchunks);
+  for (int c = 0; c < nchunks; ++c) {
+    float m = NINF;
+    for (int t = 0; t < 256; ++t) {
+      const int q = c * 256 + t;
+      if (q >= ngroups) continue;
+      for (int k = 0; k < 4; ++k) { const float v = logits[4 * q + k]; if (v != v) has_nan = true; if (v > m) m = v; }
     }
-  float S = ((part[0] + part[64]) + part[128]) + part[192];
+    float part[256];
+    for (int t = 0; t < 256; ++t) {
+      const int q = c * 256 + t;
+      part[t] = 0.f;
+      if (q < ngroups && m > NINF)
+        for (int k = 0; k < 4; ++k) part[t] = part[t] + orc_expf(logits[4 * q + k] - m);
+    }
+    for (int w = 0; w < 4; ++w)
+      for (int off = 32; off >= 1; off >>= 1) {
+        float nxt[64];
+        for (int l = 0; l < 64; ++l) nxt[l] = part[w * 64 + l] + part[w * 64 + (l ^ off)];
+        memcpy(part + w * 64, nxt, sizeof(nxt));
+      }
+    mc[c] = m;
+    sc[c] = ((part[0] + part[64]) + part[128]) + part[192];
+  }
+  float m = NINF;
+  for (int c = 0; c < nchunks; ++c) if (mc[c] > m) m = mc[c];
+  float S = 0.f;
+  for (int c = 0; c < nchunks; ++c) S = S + (mc[c] > NINF ? sc[c] * orc_expf(mc[c] - m) : 0.f);
   float inv = 1.0f / S;
   float T = 0.f;
   for (int j = 0; j < n_legal; ++j) {

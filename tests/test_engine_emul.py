@@ -34,7 +34,7 @@ def test_search_random_vs_oracle():
 
 
 def test_selfplay_trace_r8():
-    assert ec.case_selfplay_trace("emul", 8, max_traces=2) > 100
+    assert ec.case_selfplay_trace("emul", 8, max_traces=1) > 100     # the GPU suite replays every trace at both sizes
 
 
 @pytest.mark.parametrize("R,INV", [(10, 2), (13, 3)])

@@ -338,11 +338,12 @@ def main():
                                    "bytes_per_launch": fc_bytes, "flops_per_launch": flops_fc, "ms_per_launch": fc_ms,
                                    "mfma_TFLOPs": ach_fc},
         "stage_ms_per_sim_step": {"select+encode": sel_ms, "tower": tower_ms, "policy_linear": fc_ms, "expand+backup": exp_ms},
+        "stage_note": "expand+backup is k_expand_select = expansion + backup of step s and selection of step s+1; select+encode is what is left between two steps (event overhead) plus the first step's k_select",
         "tree_hbm": {"bound": "hbm", "algorithmic_bytes_per_sim": tree_bytes_per_sim(R),
                      "achieved": tree_bytes_per_sim(R) * G / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0,
                      "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": (tree_bytes_per_sim(R) * G / (tree_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if tree_ms > 0 else 0.0,
-                     "kernels": "k_select + k_expand (+ the leaf encode, done inside k_tower) -- latency-bound: one wavefront per game"},
+                     "kernels": "k_select (first step) + k_expand_select (expansion of step s fused with the selection of step s+1; the leaf encode happens inside k_tower) -- latency-bound: one wavefront per game"},
     }
     if not args.no_cpu_baseline and world == 1:      # reported baselines: rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(R, INV, model, args)

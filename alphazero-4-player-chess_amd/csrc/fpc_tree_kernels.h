@@ -977,12 +977,13 @@ __device__ inline void select_game(WaveLds &s, const DevCfg &c, const Tree &t, i
   //   ucb_i = W_i/N_i + C * sqrt( log(sqrt(N_parent)) / (1 + N_i) ) * P_i      (fp64, no contraction)
   //   strict '>' from -inf => lowest index wins ties, NaN never wins
   // Every level costs ONE dependent global round trip: the lanes that fetch the children's N/W/P also
-  // fetch each child's (first child, child count), so the chosen child's own children can be requested
-  // as soon as the argmax is known.
+  // fetch each child's (first child, child count, board-pool slot), so the chosen child's own children can
+  // be requested as soon as the argmax is known, and at the leaf both its slot and its parent's are at hand.
   int n = 0, depth = 0;
   bool fail = false;
   int *path = t.path + (size_t)g * t.path_cap;
   int c0 = t.child0[nb], nc = t.nch[nb], Nn = t.N[nb];
+  int slot = t.bslot[nb], parent_slot = -1;        // board-pool slot of node n / of its parent
   for (;;) {
     if (lane == 0 && depth < t.path_cap) path[depth] = n;
     ++depth;
@@ -990,18 +991,19 @@ __device__ inline void select_game(WaveLds &s, const DevCfg &c, const Tree &t, i
     const double L = logtab[Nn];
     const double sqrtNp = sqrt((double)Nn);
     double best = 0.0;
-    int besti = -1, best_c0 = -1, best_nc = 0, best_N = 0;
+    int besti = -1, best_c0 = -1, best_nc = 0, best_N = 0, best_slot = -1;
     for (int base = 0; base < nc; base += 64) {
       const int i = base + lane;
       double u = 0.0;
       bool valid = false;
-      int Nc = 0, cc0 = -1, cnc = 0;
+      int Nc = 0, cc0 = -1, cnc = 0, cslot = -1;
       if (i < nc) {
         Nc = t.N[nb + c0 + i];
         const double Wc = t.W[nb + c0 + i];
         const double Pc = (double)t.P[nb + c0 + i];
         cc0 = t.child0[nb + c0 + i];
         cnc = t.nch[nb + c0 + i];
+        cslot = t.bslot[nb + c0 + i];
         if (c.rules & FPC_RULES_PUCT) {
           // AlphaZero PUCT, the child's value seen from the parent: -W/N + C P sqrt(N_parent) / (1 + N)
           const double q = Nc > 0 ? -(Wc / (double)Nc) : 0.0;
@@ -1021,12 +1023,13 @@ __device__ inline void select_game(WaveLds &s, const DevCfg &c, const Tree &t, i
         if (u2 > u || (u2 == u && i2 < idx)) { u = u2; idx = i2; }
       }
       const int src = idx != 0x7fffffff ? idx - base : 0;
-      const int w_c0 = __shfl(cc0, src), w_nc = __shfl(cnc, src), w_N = __shfl(Nc, src);
-      if (idx != 0x7fffffff && (besti < 0 || u > best)) { best = u; besti = idx; best_c0 = w_c0; best_nc = w_nc; best_N = w_N; }
+      const int w_c0 = __shfl(cc0, src), w_nc = __shfl(cnc, src), w_N = __shfl(Nc, src), w_slot = __shfl(cslot, src);
+      if (idx != 0x7fffffff && (besti < 0 || u > best)) { best = u; besti = idx; best_c0 = w_c0; best_nc = w_nc; best_N = w_N; best_slot = w_slot; }
     }
     if (besti < 0) { fail = true; break; }
     n = c0 + besti;
     c0 = best_c0; nc = best_nc; Nn = best_N;
+    parent_slot = slot; slot = best_slot;
   }
   if (fail) {                                // node.cpp:72-75 throws
     if (lane == 0) { t.err[g] |= ERR_SELECT; t.alive[g] = 0; leaf_node[g] = -1; leaf_slot[g] = -1; }
@@ -1034,11 +1037,9 @@ __device__ inline void select_game(WaveLds &s, const DevCfg &c, const Tree &t, i
   }
   // ---- leaf state: the reference copies + MakeMoves a Board for every child at expansion time
   //      (node.cpp:90-91); here it is materialised the first time the node is reached.
-  int slot = t.bslot[nb + n];
   const fpc_board *pool = t.boards + (size_t)g * t.board_cap;
   if (slot < 0) {
-    const int par = t.parent[nb + n];
-    lds_load_board(&s, &pool[t.bslot[nb + par]]);
+    lds_load_board(&s, &pool[parent_slot]);
     int from;
     const int to = flat_to(c, t.mv[nb + n], &from);
     const bool moved = make_move_wave(&s.b, from, to, c);

@@ -45,6 +45,8 @@ void run_grid(int grid, int block, const std::function<void()> &body) {
       s.lane_ctx[l].uc_link = &s.main_ctx;
       makecontext(&s.lane_ctx[l], trampoline, 0);
       s.done[l] = false;
+      s.cnt[l] = 0;
+      s.stamp[0][l] = s.stamp[1][l] = 0;
     }
     for (;;) {
       bool any = false;

@@ -50,7 +50,13 @@ struct State {
   int nthreads;
   int cur;                       // running fibre == threadIdx.x
   wemu_dim3 block_idx;
-  uint64_t slot[MAX_THREADS];
+  // Collectives alternate between two exchange buffers, so ONE rendezvous each is enough (a lane can only reach
+  // a buffer's next reuse through the rendezvous in between).  Every lane counts its collectives and stamps
+  // what it posts: a source lane took part iff its stamp equals the reader's count -- lanes that left the
+  // kernel earlier (or right after posting) are told apart without a second rendezvous.
+  uint64_t slot[2][MAX_THREADS];
+  uint32_t stamp[2][MAX_THREADS];
+  uint32_t cnt[MAX_THREADS];
   Bar block_bar, wave_bar[MAX_THREADS / WAVE];
   int block_live, wave_live[MAX_THREADS / WAVE];
   std::function<void()> body;
@@ -89,11 +95,12 @@ template <class T>
 inline T exchange(T v, int src) {
   State &s = st();
   const int base = (s.cur / WAVE) * WAVE;
-  s.slot[s.cur] = to_bits(v);
+  const uint32_t c = ++s.cnt[s.cur];
+  const int p = (int)(c & 1u);
+  s.slot[p][s.cur] = to_bits(v);
+  s.stamp[p][s.cur] = c;
   wave_barrier();
-  const T r = (src >= 0 && src < WAVE && base + src < s.nthreads && !s.done[base + src]) ? from_bits<T>(s.slot[base + src]) : v;
-  wave_barrier();
-  return r;
+  return (src >= 0 && src < WAVE && base + src < s.nthreads && s.stamp[p][base + src] == c) ? from_bits<T>(s.slot[p][base + src]) : v;
 }
 }  // namespace wemu
 
@@ -114,12 +121,14 @@ inline void __syncthreads() { wemu::block_barrier(); }
 inline unsigned long long __ballot(bool p) {
   wemu::State &s = wemu::st();
   const int base = (s.cur / wemu::WAVE) * wemu::WAVE;
-  s.slot[s.cur] = p ? 1 : 0;
+  const uint32_t c = ++s.cnt[s.cur];
+  const int b = (int)(c & 1u);
+  s.slot[b][s.cur] = p ? 1 : 0;
+  s.stamp[b][s.cur] = c;
   wemu::wave_barrier();
   unsigned long long m = 0;
   for (int i = 0; i < wemu::WAVE && base + i < s.nthreads; ++i)
-    if (!s.done[base + i] && s.slot[base + i]) m |= 1ull << i;
-  wemu::wave_barrier();
+    if (s.stamp[b][base + i] == c && s.slot[b][base + i]) m |= 1ull << i;
   return m;
 }
 template <class T>

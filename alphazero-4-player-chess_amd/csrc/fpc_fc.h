@@ -12,6 +12,9 @@
 //     from LDS feeds two MFMAs (0.5 KiB of LDS per MFMA; the 8-wave / 32-column version of round 1 paid
 //     1 KiB and stalled on the LDS queue), and the fragment reads run a whole k-step (16 MFMAs, 512
 //     cycles) ahead of their use.
+//   * The weight pieces carry the non-temporal hint: 1.1 GB read once per launch would otherwise push the
+//     activations, the tower's weights and the tree out of L2 / MALL (same-box A/B: +2.6 % on the whole step,
+//     8 us of it in this kernel, 5 in k_tower, 2 in the tree kernels).
 //   * Both operands arrive by LDS-DMA (global_load_lds_dwordx4, no VGPR hop): the activations X[256][K]
 //     (12 MB, L2 resident, re-read by every column group) in full 128-byte lines into three 32 KiB stage
 //     buffers shared by the block (XOR-swizzled through the source address), the weights into a private
@@ -51,6 +54,12 @@ constexpr int FC_LDS = 3 * FC_XBUF + 4 * FC_WRING;   // 163840: the whole LDS of
 __device__ __forceinline__ void fc_dma(const void *gsrc_uniform, uint32_t lane_off, uint32_t lds_addr_uniform) {
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_addr_uniform) : "memory");
+}
+// the same with the non-temporal hint: for bytes that are read once per launch (the weight stream)
+__device__ __forceinline__ void fc_dma_nt(const void *gsrc_uniform, uint32_t lane_off, uint32_t lds_addr_uniform) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_addr_uniform) : "memory");
 }
 
@@ -111,8 +120,8 @@ __global__ void __launch_bounds__(FC_THREADS, 1) k_fc(FcArgs g) {
     const int sc = s < S ? s : S - 1;
     const unsigned char *src = wbase + (long)(4 * sc + ks) * wkstep;
     const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(lds_w + ((s & 1) * 8 + ks * 2) * 1024);
-    fc_dma(src, wlane, dst);
-    fc_dma(src + 1024, wlane, dst + 1024);
+    fc_dma_nt(src, wlane, dst);
+    fc_dma_nt(src + 1024, wlane, dst + 1024);
   };
   auto xfrag = [&](int b, int t, const unsigned char *ab, int ks) {
     xf[b][t] = *reinterpret_cast<const u32x4_t *>(ab + lds_off<64>(t * 32 + (lane & 31), ks * 2 + (lane >> 5)));

@@ -1,12 +1,15 @@
 // fpc_tree_kernels.h -- CDNA4 kernels for the tree side of MCTS.search: one 64-lane wavefront per
 // concurrent game (block = 1 wave, grid = games), board state staged in LDS.
 //
-//   k_board_ops   batched Board::GetLegalMoves / GetGameResult / TakeAction / encode / mask
-//   k_select      Node::ChooseLeaf: PUCT descent (wave argmax), lazy leaf-board materialisation,
-//                 GetGameResult + GetLegalMoves on the leaf, terminal backup        (node.cpp:19-78)
-//   k_encode      Board::GetEncodedStates incl. the batch-wide rot90                 (board.cpp:305-356)
-//   k_expand      softmax / ParseActionspace / mask / renormalise, BackpropagateNodes, ExpandNodes
-//                                                                                    (mcts.py:67-89)
+//   k_board_ops      batched Board::GetLegalMoves / GetGameResult / TakeAction / encode / mask
+//   k_select         Node::ChooseLeaf: PUCT descent (wave argmax), lazy leaf-board materialisation,
+//                    GetGameResult + GetLegalMoves on the leaf, terminal backup        (node.cpp:19-78)
+//   k_encode         Board::GetEncodedStates incl. the batch-wide rot90                 (board.cpp:305-356)
+//   k_softmax_partials  per-chunk softmax statistics of a logits row (external evaluators; the internal
+//                    policy Linear's k_fc_reduce leaves the same records)                (mcts.py:67)
+//   k_expand         ParseActionspace / mask / renormalise from those statistics, BackpropagateNodes,
+//                    ExpandNodes                                                        (mcts.py:67-89)
+//   k_expand_select  k_expand of simulation step s + k_select of step s+1 in one launch
 //
 // Reference semantics (file:line relative to /root/reference/src/cpp) are restated per function.
 // Nothing here is translated from the reference: its board is a pointer-rich mailbox + std::vector

@@ -56,3 +56,44 @@ def test_fixed_rules_and_root_noise_vs_oracle(R):
     """N4: non-strict rule set + root Dirichlet noise, engine vs oracle under the same rules"""
     n_promo, n_castle = ec.case_fixed_rules_vs_oracle("emul", R, n_games=3, plies=70 if R == 8 else 30, sims=16)
     assert (n_promo > 0) if R == 8 else (n_castle > 0)
+
+
+def test_step_entry_points_refuse_bad_calls():
+    """Error behaviour of the step-wise search entry points (fpc_search_select / expand / expand_select):
+    no search begun -> ESTATE; null logits -> EINVAL; more simulations than max_sims -> ECAPACITY."""
+    import numpy as np
+    import evaluators
+    import fpc_ffi
+    from fpc_testlib import gold, make_engine
+    R = 8
+    g = gold(R)
+    st = g["start"]
+    eng = make_engine("emul", R, g["INV"], max_games=2, max_sims=3)
+    try:
+        with pytest.raises(RuntimeError, match="fpc_search_begin"):
+            eng.search_select()
+        with pytest.raises(RuntimeError, match="fpc_search_begin"):
+            eng.search_expand_select(0, 0)
+        roots = [fpc_ffi.board_from_dict(R, st["turn"], [tuple(e) for e in st["dict"]], _lib=eng.L) for _ in range(2)]
+        eng.search_begin(roots, 3.0)
+        n_live, enc_ptr = eng.search_select()
+        assert n_live == 2
+        with pytest.raises(RuntimeError, match="null"):
+            eng.search_expand_select(0, 0)
+        ev = evaluators.make("hash", R)
+        import ctypes as C
+        for _ in range(2):      # simulations 2 and 3 through the fused entry point
+            enc = np.ctypeslib.as_array(C.cast(enc_ptr, C.POINTER(C.c_float)), shape=(2, 24, R, R))
+            lg, v = ev(enc)
+            lg = np.ascontiguousarray(lg, dtype=np.float32); v = np.ascontiguousarray(v, dtype=np.float32)
+            n_live, enc_ptr = eng.search_expand_select(lg.ctypes.data, v.ctypes.data)
+        enc = np.ctypeslib.as_array(C.cast(enc_ptr, C.POINTER(C.c_float)), shape=(2, 24, R, R))
+        lg, v = ev(enc)
+        lg = np.ascontiguousarray(lg, dtype=np.float32); v = np.ascontiguousarray(v, dtype=np.float32)
+        with pytest.raises(RuntimeError, match="max_sims"):        # a 4th selection would exceed max_sims = 3
+            eng.search_expand_select(lg.ctypes.data, v.ctypes.data)
+        eng.search_expand(lg.ctypes.data, v.ctypes.data)            # the plain expansion of the last one is fine
+        res = eng.search_results(roots=roots)
+        assert list(res["sims_done"]) == [3, 3] and list(res["root_n"]) == [4, 4]
+    finally:
+        eng.close()

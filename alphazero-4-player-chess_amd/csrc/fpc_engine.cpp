@@ -66,6 +66,7 @@ struct fpc_engine {
   int *d_tgame = nullptr;           // [max_games] game ids of one collect / set_z call
   float *d_tz = nullptr;            // [2][max_games]
   float *d_noise = nullptr;         // [max_games][FPC_MAX_MOVES] root-noise gamma draws (N4)
+  int noise_n = 0;                  // rows uploaded by fpc_search_set_root_noise: a search must have exactly that many games
   void *comm = nullptr;             // ncclComm_t
   int comm_rank = 0, comm_world = 1;
   fpc_tuple *d_gather = nullptr;    // [world][gather_stride]
@@ -227,7 +228,7 @@ void resolve_marks(fpc_engine *e) {
 
 extern "C" {
 
-int fpc_abi_version(void) { return 5; }
+int fpc_abi_version(void) { return 6; }
 
 const char *fpc_last_error(const fpc_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
@@ -446,6 +447,8 @@ int fpc_search_begin(fpc_engine *e, const fpc_board *roots, int n_games, double 
   if (!e || !roots || n_games < 1) return fail(e, FPC_EINVAL, "bad argument");
   USE_DEV(e);
   if (n_games > e->cfg.max_games) return fail(e, FPC_EINVAL, "n_games %d > max_games %d", n_games, e->cfg.max_games);
+  if (e->t.noise && e->noise_n != n_games)
+    return fail(e, FPC_EINVAL, "root noise was uploaded for %d games, this search has %d: call fpc_search_set_root_noise again (or with NULL)", e->noise_n, n_games);
   int r;
   if ((r = check_boards(e, roots, n_games))) return r;
   e->G = n_games;
@@ -685,6 +688,8 @@ int fpc_nn_forward(fpc_engine *e, const float *enc_dev, int n, float *logits_dev
 // training tuples
 int fpc_tuples_reserve(fpc_engine *e, int capacity) {
   if (!e || capacity < 0) return fail(e, FPC_EINVAL, "bad argument");
+  // fpc_tuple carries a child's visit count (1 + its simulations, Q1) as u16
+  if (e->cfg.max_sims > 65534) return fail(e, FPC_EUNSUPPORTED, "training tuples hold visit counts as u16: max_sims %d > 65534", e->cfg.max_sims);
   USE_DEV(e);
   if (e->d_tuples) {
     (void)hipFree(e->d_tuples);
@@ -769,7 +774,10 @@ extern "C++" Rccl &rccl() {
   if (r.h || !r.err.empty()) return r;
   // FPC_RCCL_LIB: the host layer names the copy that belongs to the HIP runtime already in the process
   // (PyTorch-ROCm ships its own librccl.so next to its libamdhip64.so)
-  if (const char *env = getenv("FPC_RCCL_LIB")) r.h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+  if (const char *env = getenv("FPC_RCCL_LIB")) {
+    r.h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+    if (!r.h) { r.err = std::string("FPC_RCCL_LIB=") + env + " cannot be loaded: " + (dlerror() ? dlerror() : ""); return r; }   // an explicit choice: no silent substitute
+  }
   const char *names[] = {"librccl.so", "librccl.so.1"};
   for (const char *n : names) if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
   for (const char *n : names) if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -789,6 +797,15 @@ int comm_fail(fpc_engine *e, const char *what, int rc) {
 }
 }  // namespace
 #endif
+
+int fpc_comm_available(void) {
+#ifdef FPC_EMUL
+  return fail(nullptr, FPC_EUNSUPPORTED, "RCCL exists only in the gfx950 build");
+#else
+  Rccl &r = rccl();
+  return r.err.empty() ? 0 : fail(nullptr, FPC_ECOMM, "%s", r.err.c_str());
+#endif
+}
 
 int fpc_comm_unique_id(void *id128) {
   if (!id128) return FPC_EINVAL;
@@ -855,8 +872,15 @@ int fpc_allgather_tuples(fpc_engine *e, int *counts_out, int *total_out) {
   HIPCHK(e, hipStreamSynchronize(e->stream));
   long long mx = 1;
   for (int i = 0; i < W; ++i) mx = std::max(mx, cnt[i]);
-  if (mx > e->tuple_cap) {     // the send buffer must hold the padded count
-    return fail(e, FPC_ECAPACITY, "another rank holds %lld tuples, more than this engine's tuple capacity %d (reserve the same capacity on every rank)", mx, e->tuple_cap);
+  if (mx > e->tuple_cap) {     // the send buffer must hold the padded count: every rank knows mx, so each grows its own
+    fpc_tuple *bigger = nullptr;   // buffer here and all of them still enter the payload collective together
+    int rr;
+    if ((rr = dalloc(e, &bigger, (size_t)mx))) return rr;
+    if (e->tuple_count) HIPCHK(e, hipMemcpyAsync(bigger, e->d_tuples, (size_t)e->tuple_count * sizeof(fpc_tuple), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->d_tuples) { (void)hipFree(e->d_tuples); e->allocs.erase(std::find(e->allocs.begin(), e->allocs.end(), (void *)e->d_tuples)); }
+    e->d_tuples = bigger;
+    e->tuple_cap = (int)mx;
   }
   // 2. payload, padded to the largest count: ONE collective per episode (latency-bound)
   if ((long long)W * mx > e->gather_cap) {
@@ -928,7 +952,7 @@ int fpc_set_rules(fpc_engine *e, int rules) {
 int fpc_search_set_root_noise(fpc_engine *e, const float *gamma, int n_games, float eps) {
   if (!e) return FPC_EINVAL;
   USE_DEV(e);
-  if (!gamma) { e->t.noise = nullptr; e->t.noise_eps = 0.f; return 0; }
+  if (!gamma) { e->t.noise = nullptr; e->t.noise_eps = 0.f; e->noise_n = 0; return 0; }
   if (n_games < 1 || n_games > e->cfg.max_games || !(eps >= 0.f && eps <= 1.f)) return fail(e, FPC_EINVAL, "bad root-noise arguments");
   int r;
   if (!e->d_noise && (r = dalloc(e, &e->d_noise, (size_t)e->cfg.max_games * FPC_MAX_MOVES))) return r;
@@ -936,6 +960,7 @@ int fpc_search_set_root_noise(fpc_engine *e, const float *gamma, int n_games, fl
   HIPCHK(e, hipStreamSynchronize(e->stream));
   e->t.noise = e->d_noise;
   e->t.noise_eps = eps;
+  e->noise_n = n_games;
   return 0;
 }
 
@@ -943,6 +968,15 @@ int fpc_set_timing(fpc_engine *e, int enabled) {
   if (!e) return FPC_EINVAL;
   e->timing = enabled != 0;
   return 0;
+}
+const char *fpc_nn_kernel(fpc_engine *e) {
+#ifdef FPC_EMUL
+  (void)e;
+  return "";
+#else
+  if (!e || !e->nn.loaded) return "";
+  return e->nn.use_tower ? "k_tower" : e->nn.use_tower256 ? "k_tower256" : "k_conv3x3";
+#endif
 }
 void *fpc_stream(fpc_engine *e) { return e ? (void *)e->stream : nullptr; }
 

@@ -1157,6 +1157,7 @@ __device__ __forceinline__ void expand_finish(WaveLds &s, const Tree &t, int g, 
     __syncthreads();
   }
   const float SG = s.scal_f;
+  const bool add_noise = noisy && SG > 0.f;      // rows without positive mass (never uploaded, all-zero draws) leave the priors alone
   // BackpropagateNodes (mcts.py:78) before ExpandNodes (mcts.py:79)
   backprop_path(t, nb, g, value[g]);
   if (lane == 0) t.sims_done[g] += 1;
@@ -1169,7 +1170,7 @@ __device__ __forceinline__ void expand_finish(WaveLds &s, const Tree &t, int g, 
     bool nz = false;
     if (j < nl) {
       pr = fdiv_rn(s.pri[j], T);
-      if (noisy) pr = (1.0f - t.noise_eps) * pr + t.noise_eps * fdiv_rn(t.noise[(size_t)g * FPC_MAX_MOVES + j], SG);
+      if (add_noise) pr = (1.0f - t.noise_eps) * pr + t.noise_eps * fdiv_rn(t.noise[(size_t)g * FPC_MAX_MOVES + j], SG);
       nz = pr != 0.f;
     }
     const unsigned long long bal = __ballot(nz);

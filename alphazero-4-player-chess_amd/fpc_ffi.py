@@ -98,6 +98,8 @@ _SIGS = {
     "fpc_comm_unique_id": (C.c_int, [C.c_void_p]),
     "fpc_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "fpc_comm_destroy": (C.c_int, [C.c_void_p]),
+    "fpc_comm_available": (C.c_int, []),
+    "fpc_nn_kernel": (C.c_char_p, [C.c_void_p]),
     "fpc_allgather_tuples": (C.c_int, [C.c_void_p, P(C.c_int), P(C.c_int)]),
     "fpc_gathered_read": (C.c_int, [C.c_void_p, P(Tuple), C.c_int, C.c_int]),
 }
@@ -349,17 +351,25 @@ class Engine:
     def comm_init(self, id128, rank, world):
         buf = (C.c_char * 128).from_buffer_copy(bytes(id128))
         self._chk(self.L.fpc_comm_init(self.h, buf, rank, world))
+        self.comm_world = world
+
+    def allgather_tuples_device(self):
+        """episode end: RCCL all-gather of every rank's tuples, driven from the C++ host; the gathered
+        tuples stay on the device.  Returns (per-rank counts, total)."""
+        counts, total = (C.c_int * max(getattr(self, 'comm_world', 1), 1))(), C.c_int()
+        self._chk(self.L.fpc_allgather_tuples(self.h, counts, C.byref(total)))
+        return counts, total.value
+
+    def gathered_read(self, total):
+        arr = (Tuple * max(total, 1))()
+        if total:
+            self._chk(self.L.fpc_gathered_read(self.h, arr, 0, total))
+        return arr
 
     def allgather_tuples(self):
-        """episode end: RCCL all-gather of every rank's tuples, driven from the C++ host.
-        Returns (per-rank counts, ctypes array of all tuples in rank order)."""
-        w = C.c_int * 64
-        counts, total = w(), C.c_int()
-        self._chk(self.L.fpc_allgather_tuples(self.h, counts, C.byref(total)))
-        arr = (Tuple * max(total.value, 1))()
-        if total.value:
-            self._chk(self.L.fpc_gathered_read(self.h, arr, 0, total.value))
-        return counts, arr, total.value
+        """(per-rank counts, ctypes array of all tuples in rank order, total)"""
+        counts, total = self.allgather_tuples_device()
+        return counts, self.gathered_read(total), total
 
 
 def board_from_dict(R, turn, entries, castle=None, _lib=None):

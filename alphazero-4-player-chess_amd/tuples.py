@@ -82,19 +82,35 @@ def records_of(arr, n, R):
 
 def exchange(eng, group=None):
     """Episode-end all-gather of the tuples collected on this rank's engine.  Returns the
-    records of ALL ranks, rank-major.  With an RCCL communicator on the engine (fpc_comm_init; bench.py
+    records of ALL ranks, rank-major.  With an RCCL communicator on the engine (init_comm; bench.py
     --gpus N) the collective is issued by the C++ host on device memory; otherwise (gloo, CPU tests)
     the same PODs travel through torch.distributed as bytes."""
+    return parse_raw(eng, exchange_raw(eng, group))
+
+
+def exchange_raw(eng, group=None):
+    """The collective of `exchange` alone (what bench.py times): the gathered tuples stay where the
+    collective left them (device memory for the RCCL path, byte blobs for the torch.distributed one;
+    nothing at all in a single process).  `parse_raw` turns the result into records."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        arr, n = eng.tuples_read()
-        return records_of(arr, n, eng.R)
+        return {"kind": "local", "ranks": 1}
     if getattr(eng, "has_comm", False):
-        _counts, arr, total = eng.allgather_tuples()
-        return records_of(arr, total, eng.R)
+        counts, total = eng.allgather_tuples_device()
+        return {"kind": "rccl", "ranks": eng.comm_world, "counts": [int(counts[i]) for i in range(eng.comm_world)], "total": total}
     arr, n = eng.tuples_read()
     payload = bytes(memoryview(arr).cast("B")[:n * C.sizeof(fpc_ffi.Tuple)]) if n else b""
+    blobs = all_gather_bytes(payload, group=group)
+    return {"kind": "torch", "ranks": len(blobs), "blobs": blobs}
+
+
+def parse_raw(eng, raw):
+    if raw["kind"] == "local":
+        arr, n = eng.tuples_read()
+        return records_of(arr, n, eng.R)
+    if raw["kind"] == "rccl":
+        return records_of(eng.gathered_read(raw["total"]), raw["total"], eng.R)
     out = []
-    for blob in all_gather_bytes(payload, group=group):
+    for blob in raw["blobs"]:
         m = len(blob) // C.sizeof(fpc_ffi.Tuple)
         if m:
             out += records_of((fpc_ffi.Tuple * m).from_buffer_copy(blob), m, eng.R)
@@ -102,15 +118,55 @@ def exchange(eng, group=None):
 
 
 def init_comm(eng, device=None, group=None):
-    """RCCL communicator for `eng`, the 128-byte id travelling over the existing torch.distributed group"""
+    """RCCL communicator for `eng`; the 128-byte id travels over the existing torch.distributed group.
+
+    Collective-safe: every rank runs the same sequence of torch.distributed collectives whatever fails
+    where, and all ranks leave with the same answer.  Returns (True, "") when EVERY rank holds a
+    communicator; otherwise no rank keeps one (fpc_comm_destroy everywhere) and the result is
+    (False, reason) on every rank -- the caller then either stops (bench.py --backend nccl) or uses the
+    torch.distributed path of `exchange`.
+      1. every rank probes librccl (fpc_comm_available) and the verdicts are MIN-reduced, so nobody
+         enters ncclCommInitRank -- which blocks until all ranks arrive -- unless everybody can;
+      2. rank 0 makes the id; the broadcast carries a status byte in front of it and always runs;
+      3. after fpc_comm_init a success flag is MIN-reduced."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     dev = device if device is not None else "cpu"
-    idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+    L = eng.L
+
+    def all_ok(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return bool(int(t.item()))
+
+    why = ""
+    ok = L.fpc_comm_available() == 0
+    if not ok:
+        why = "rank %d: %s" % (rank, (L.fpc_last_error(None) or b"").decode())
+    if not all_ok(ok):
+        return False, why or "librccl is not available on another rank"
+    msg = torch.zeros(129, dtype=torch.uint8)
     if rank == 0:
-        idt = torch.frombuffer(bytearray(fpc_ffi.comm_unique_id(eng.L)), dtype=torch.uint8).to(dev)
-    dist.broadcast(idt, 0, group=group)
-    eng.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+        try:
+            msg[1:] = torch.frombuffer(bytearray(fpc_ffi.comm_unique_id(L)), dtype=torch.uint8)
+            msg[0] = 1
+        except RuntimeError as exc:
+            why = "rank 0: %s" % (exc,)
+    msg = msg.to(dev)
+    dist.broadcast(msg, 0, group=group)
+    msg = msg.cpu()
+    if int(msg[0]) != 1:
+        return False, why or "rank 0 could not create the ncclUniqueId"
+    ok = True
+    try:
+        eng.comm_init(bytes(msg[1:].numpy().tobytes()), rank, world)
+    except RuntimeError as exc:
+        ok, why = False, "rank %d: %s" % (rank, exc)
+    if not all_ok(ok):
+        L.fpc_comm_destroy(eng.h)
+        eng.has_comm = False
+        return False, why or "fpc_comm_init failed on another rank"
     eng.has_comm = True
+    return True, ""
 
 
 def dense_batch(eng, recs):

@@ -88,15 +88,18 @@ def pick_moves(res, rng, temperature):
     return flats
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, choices=[1, 3], default=None,
+                    help="BASELINE.json preset: 1 = configs[1] (256 games x 400 sims, ResNet(10,128), the default), "
+                         "3 = configs[3] (ResNet(20,256), 800 sims/move, fp16)")
     ap.add_argument("--games", type=int, default=256, help="concurrent games per GPU")
-    ap.add_argument("--sims", type=int, default=400)
-    ap.add_argument("--blocks", type=int, default=10)
-    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--sims", type=int, default=None)
+    ap.add_argument("--blocks", type=int, default=None)
+    ap.add_argument("--hidden", type=int, default=None)
     ap.add_argument("--board", type=int, default=14)
     ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"])
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the extra measurement with the other 16-bit operand type")
@@ -108,15 +111,107 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N>1 rehearsal on a single-GPU box: every rank uses device 0 (use with --backend gloo)")
-    args = ap.parse_args()
+    ap.add_argument("--launch-dry-run", action="store_true",
+                    help="N>1 without an external launcher: start the N ranks, have each report its environment and exit (no GPU, no torch)")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="seconds the self-launcher waits for its ranks")
+    args = ap.parse_args(argv)
+    preset = {1: (400, 10, 128), 3: (800, 20, 256)}[args.config or 1]
+    args.sims = preset[0] if args.sims is None else args.sims
+    args.blocks = preset[1] if args.blocks is None else args.blocks
+    args.hidden = preset[2] if args.hidden is None else args.hidden
+    return args
 
+
+def workload_label(G, sims, blocks, hidden, R):
+    """which BASELINE.json config (if any) these arguments are"""
+    shape = "%d concurrent games/GPU x %d sims/move, ResNet(%d,%d), %dx%d board, start=%s" % (
+        G, sims, blocks, hidden, R, R, {14: "STANDARD", 8: "EIGHT_SIMPLE"}.get(R, "%dx%d layout" % (R, R)))
+    if (G, sims, blocks, hidden, R) == (256, 400, 10, 128, 14):
+        return "configs[1]: " + shape
+    if (sims, blocks, hidden, R) == (800, 20, 256, 14):
+        return "configs[3]: " + shape
+    return "custom (not a BASELINE.json config): " + shape
+
+
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` without torchrun: this process becomes the launcher.  It has made no HIP /
+    torch.cuda call (torch is not even imported yet), starts one child per GPU with the torchrun
+    environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and waits; rank 0's
+    stdout (the one JSON line) passes through.  Any child that fails takes the job down: the others
+    are terminated by PID and the launcher exits non-zero."""
+    import signal
+    import socket
+    import subprocess
+    n = args.gpus
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "FPC_BENCH_LAUNCHER_PID": str(os.getpid())})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = subprocess.PIPE if args.launch_dry_run else None
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out))
+    deadline = time.time() + args.launch_timeout
+    rc, failed = 0, None
+    live = set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc, failed = (code if code > 0 else 1), r
+                break
+        if time.time() > deadline:
+            rc, failed = 124, -1
+        if live and rc == 0:
+            time.sleep(0.05)
+    if rc != 0:
+        for r in sorted(live):          # exactly the children this launcher started
+            procs[r].send_signal(signal.SIGTERM)
+        t_end = time.time() + 10
+        for r in sorted(live):
+            try:
+                procs[r].wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        print("bench.py launcher: rank %s %s; job stopped (exit %d)" %
+              (failed if failed >= 0 else "?", "failed" if failed >= 0 else "timed out", rc), file=sys.stderr, flush=True)
+    if args.launch_dry_run:
+        probes = []
+        for p_ in procs:
+            txt = p_.stdout.read().decode() if p_.stdout else ""
+            for line in txt.splitlines():
+                if line.startswith("{"):
+                    probes.append(json.loads(line)["launch_probe"])
+        print(json.dumps({"launched": n, "exit": rc, "ranks": sorted(probes, key=lambda d: d["rank"])}), flush=True)
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))         # before any torch / HIP call in this process
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if args.launch_dry_run:
+        print(json.dumps({"launch_probe": {"rank": rank, "local_rank": local, "world": world,
+                                           "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")),
+                                           "ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}}), flush=True)
+        sys.exit(int(os.environ.get("FPC_BENCH_PROBE_EXIT_RANK%d" % rank, "0")))
     import torch
     import torch.distributed as dist
     if args.rehearse_one_gpu:
         local = 0
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"      # where the few scalar reductions of this script live
     if world > 1:
         torch.cuda.set_device(local)
         if args.backend == "nccl":
@@ -138,13 +233,15 @@ def main():
     eng = fpc_ffi.Engine(R, INV, max_games=G, max_sims=sims, device=local, nn_dtype=dt)
     eng.set_policy_mode(args.policy_head == "legal")
     eng.load_weights(weights.export_weights(model, dt))
+    nn_kernel = (eng.L.fpc_nn_kernel(eng.h) or b"").decode()
     turn, entries = positions.start_entries(R)
     start = fpc_ffi.board_from_dict(R, turn, entries)
     boards = [fpc_ffi.clone_board(start) for _ in range(G)]
     rng = np.random.default_rng(1234 + rank)
-    # episode bookkeeping: every concurrent game carries a job-wide unique id; tuples are built on the
-    # device by fpc_collect_tuples, z is assigned when a game ends (alphazero.py:128-137, quirk Q12) or,
-    # for games still running at the end, by the material heuristic (alphazero.py:161-175)
+    # episode bookkeeping: every concurrent game carries a job-wide unique id (id mod world = the rank
+    # that played it); tuples are built on the device by fpc_collect_tuples, z is assigned when a game
+    # ends (alphazero.py:128-137, quirk Q12) or, for games still running at the end, by the material
+    # heuristic (alphazero.py:161-175)
     state = {"ids": [g * world + rank for g in range(G)], "next": G, "ply": [0] * G, "step": 0}
     eng.tuples_reserve(G * (args.steps + 1))
 
@@ -185,28 +282,40 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def reduce_pair(elapsed_s, count):
+        """max-over-ranks time, sum-over-ranks count"""
+        if world == 1:
+            return elapsed_s, count
+        tt = torch.tensor([elapsed_s], device=red_dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ts = torch.tensor([float(count)], device=red_dev, dtype=torch.float64)
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        return float(tt.item()), int(ts.item())
+
     def gather_tuples():
         """episode end: z of the games still running (heuristic), then the all-gather of this rank's
-        tuples over RCCL/xGMI, issued by the engine's C++ host."""
+        tuples over RCCL/xGMI, issued by the engine's C++ host.  Only the collective runs
+        here (inside the timed region); the records are parsed afterwards, at every N alike."""
         ids, z0, z1 = [], [], []
         for g in range(G):
             h = eng.L.fpc_board_heuristic(boards[g], boards[g].turn & 1) * 0.02
             ids.append(state["ids"][g]); z0.append(h if (boards[g].turn & 1) == 0 else -h); z1.append(h if (boards[g].turn & 1) == 1 else -h)
         eng.tuples_set_z(ids, z0, z1)
-        if world == 1:
-            return eng.tuples_count() * 1280
-        recs = tuples_mod.exchange(eng)
-        return len(recs) * 1280
+        return tuples_mod.exchange_raw(eng)
 
-    exchange_path = "single process"
+    exchange = {"path": "single process (no exchange)", "backend": None}
     if world > 1:
-        exchange_path = "torch.distributed all_gather of the native tuple PODs (%s)" % args.backend
+        exchange = {"path": "torch.distributed all_gather of the native tuple PODs", "backend": args.backend}
         if args.backend == "nccl":
-            try:      # the engine's own RCCL communicator (C++ host); its 128-byte id travels over torch.distributed
-                tuples_mod.init_comm(eng, device=torch.device("cuda", local))
-                exchange_path = "fpc_allgather_tuples: ncclAllGather issued by the engine's C++ host"
-            except RuntimeError as exc:
-                exchange_path += " [fpc_comm_init failed: %s]" % (exc,)
+            # the engine's own RCCL communicator (C++ host); its 128-byte id travels over torch.distributed.
+            # init_comm gives every rank the same verdict; with --backend nccl a failure stops the job
+            ok, why = tuples_mod.init_comm(eng, device=torch.device("cuda", local))
+            if not ok:
+                if rank == 0:
+                    print("bench.py: fpc_comm_init failed, job stopped (no silent fallback at --backend nccl): %s" % why, file=sys.stderr, flush=True)
+                dist.destroy_process_group()
+                sys.exit(3)
+            exchange["path"] = "fpc_allgather_tuples: ncclAllGather issued by the engine's C++ host"
 
     for _ in range(args.warmup):
         step(False)
@@ -217,19 +326,22 @@ def main():
     total = 0
     for _ in range(args.steps):
         total += step(True)
-    gathered = gather_tuples()
+    raw = gather_tuples()
     sync()
     t1 = time.perf_counter()
     eng.set_timing(False)
     elapsed = t1 - t0
     st = eng.stats()
-    if world > 1:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        ts = torch.tensor([float(total)], device="cuda", dtype=torch.float64)
-        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
-        total = int(ts.item())
+    elapsed, total = reduce_pair(elapsed, total)
+    # outside the timed region: what arrived?  ranks_seen = distinct source ranks among the gathered game ids
+    recs = tuples_mod.parse_raw(eng, raw)
+    exchange["tuples_gathered"] = len(recs)
+    exchange["bytes_gathered"] = len(recs) * 1280
+    exchange["ranks_seen"] = len({r["game"] % world for r in recs})
+    exchange["ranks_in_communicator"] = raw.get("ranks", 1)
+    if exchange["ranks_seen"] != world:
+        print("bench.py: tuples of %d ranks arrived, world is %d" % (exchange["ranks_seen"], world), file=sys.stderr, flush=True)
+        sys.exit(4)
 
     # Reported beside the headline, never as `value`: the same job with the opt-in legal-only policy head
     # (fpc_set_policy_mode(FPC_POLICY_LEGAL)): the policy Linear is evaluated only at
@@ -244,20 +356,13 @@ def main():
         for _ in range(3):
             atotal += step(False)
         sync()
-        aelapsed = time.perf_counter() - a0
+        aelapsed, atotal = reduce_pair(time.perf_counter() - a0, atotal)
         eng.set_policy_mode(False)
-        if world > 1:
-            at = torch.tensor([aelapsed], device="cuda", dtype=torch.float64)
-            dist.all_reduce(at, op=dist.ReduceOp.MAX)
-            aelapsed = float(at.item())
-            as_ = torch.tensor([float(atotal)], device="cuda", dtype=torch.float64)
-            dist.all_reduce(as_, op=dist.ReduceOp.SUM)
-            atotal = int(as_.item())
         alt = {"value": atotal / aelapsed, "unit": "sims/s", "steps": 3,
                "note": "NOT the headline: policy Linear evaluated only at the leaves' legal moves (softmax denominator "
                        "cancels in mask+renormalise); priors equal the full head's within 2e-5 (f32 rounding), so a PUCT near-tie can "
-                       "resolve differently: tests/test_nn_gpu.py::test_legal_only_policy_head_matches_full reports how many games "
-                       "searched differently (none in the recorded runs); opt-in via fpc_set_policy_mode"}
+                       "resolve differently: tests/test_nn_gpu.py::test_legal_only_policy_head_matches_full bounds how many games "
+                       "may search differently; opt-in via fpc_set_policy_mode"}
 
     # Reported beside the headline, never as `value`: the same job with the OTHER 16-bit MFMA operand
     # type (BASELINE configs[1] names bf16; the headline is fp16 because only fp16 meets the 1e-3 logits bar)
@@ -279,20 +384,14 @@ def main():
         for _ in range(4):
             btotal += step(False)
         sync()
-        belapsed = time.perf_counter() - b0
-        if world > 1:
-            bt = torch.tensor([belapsed], device="cuda", dtype=torch.float64)
-            dist.all_reduce(bt, op=dist.ReduceOp.MAX)
-            belapsed = float(bt.item())
-            bs = torch.tensor([float(btotal)], device="cuda", dtype=torch.float64)
-            dist.all_reduce(bs, op=dist.ReduceOp.SUM)
-            btotal = int(bs.item())
+        belapsed, btotal = reduce_pair(time.perf_counter() - b0, btotal)
         alt_dtype = {"dtype": other, "value": btotal / belapsed, "unit": "sims/s", "steps": 4,
                      "note": "same workload, other 16-bit MFMA operand type; see float_parity for which type meets the 1e-3 logits bar"}
     eng.close()
 
     if rank != 0:
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
@@ -314,27 +413,41 @@ def main():
         pmc = json.load(open(os.path.join(HERE, "profiles", "pmc_summary.json")))
     except Exception:
         pass
+
+    def pmc_traffic(kernels, shape_key):
+        """counter HBM bytes per launch of exactly these kernels on exactly this network shape, or None:
+        profiles/pmc_summary.json is keyed by shape ("r14_b10_h128") since round 3"""
+        ent = pmc.get(shape_key, {})
+        vals = [ent.get(k, {}).get("hbm_bytes") for k in kernels]
+        return sum(vals) if vals and all(v is not None for v in vals) else None
+
+    shape_key = "r%d_b%d_h%d_g%d" % (R, Nb, F, G)
+    tower_desc = {"k_tower": "k_tower (residual tower megakernel, hidden 128, LDS-resident activations)",
+                  "k_tower256": "k_tower256 (residual tower megakernel, hidden 256, LDS-resident activations)",
+                  "k_conv3x3": "k_conv3x3 x %d launches (per-layer implicit GEMM, activations through L2) + k_value_tail" % (2 * Nb + 3)}.get(nn_kernel, nn_kernel)
+    fc_kernels = ["k_fc"] + (["k_fc_reduce"] if st.get("fc_reduce_launch", 1) else [])
     tree_ms = sel_ms + exp_ms
+    label = workload_label(G, sims, Nb, F, R)
     out = {
-        "metric": baseline_metric(),
+        "metric": baseline_metric() if label.startswith("configs[1]") else "MCTS simulations/sec (whole node), %d games x %d sims, %d-block/%d-filter ResNet" % (G, sims, Nb, F),
         "value": total / elapsed, "unit": "sims/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "configs[1]: %d concurrent games/GPU x %d sims/move, ResNet(%d,%d), %dx%d board, start=%s"
-                   % (G, sims, args.blocks, args.hidden, R, R, "STANDARD" if R == 14 else "default"),
-                   "games_per_gpu": G, "sims_per_move": sims, "board": R, "parallelism": "games sharded, %d/GPU" % G,
-                   "tuple_allgather_bytes": gathered, "tuple_exchange": exchange_path},
-        # dominant kernel: k_tower = stem + 2*Nb residual convs + both head convs, one launch per network forward
+        "config": {"workload": label,
+                   "games_per_gpu": G, "sims_per_move": sims, "blocks": Nb, "hidden": F, "board": R,
+                   "parallelism": "games sharded, %d/GPU" % G, "ranks": world,
+                   "tuple_exchange": exchange},
+        # dominant kernel: the residual tower (stem + 2*Nb residual convs + both head convs), one launch per network forward
         "roofline": {"bound": "mfma", "achieved": ach_tower, "peak": peak, "unit": "TFLOP/s", "frac": ach_tower / peak,
-                     "traffic": pmc.get("k_tower", {}).get("hbm_bytes"),
-                     "kernel": "k_tower (residual tower megakernel, LDS-resident activations)",
+                     "traffic": pmc_traffic([nn_kernel], shape_key),
+                     "kernel": tower_desc,
                      "flops_per_launch": flops_tower, "ms_per_launch": tower_ms},
         # the policy Linear at M = 256: 255 FLOP per weight byte, below the 312 FLOP/B ridge -> HBM-bound.
         # algorithmic bytes = the 16-bit weight matrix read once + X read once + f32 logits written once
         "roofline_policy_linear": {"bound": "hbm", "achieved": fc_bytes / (fc_ms * 1e-3) / 1e9 if fc_ms > 0 else 0.0, "peak": PEAK_HBM_GBS,
                                    "unit": "GB/s", "frac": (fc_bytes / (fc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if fc_ms > 0 else 0.0,
-                                   "traffic": (pmc.get("k_fc", {}).get("hbm_bytes", 0) + pmc.get("k_fc_reduce", {}).get("hbm_bytes", 0)) or None,
-                                   "kernel": "k_fc + k_fc_reduce (weight-streaming Linear, 1.1 GB of 16-bit weights per launch)",
+                                   "traffic": pmc_traffic(fc_kernels, shape_key),
+                                   "kernel": " + ".join(fc_kernels) + " (weight-streaming Linear, %.2f GB of 16-bit weights per launch)" % (2.0 * Np * Kp / 1e9),
                                    "bytes_per_launch": fc_bytes, "flops_per_launch": flops_fc, "ms_per_launch": fc_ms,
                                    "mfma_TFLOPs": ach_fc},
         "stage_ms_per_sim_step": {"select+encode": sel_ms, "tower": tower_ms, "policy_linear": fc_ms, "expand+backup": exp_ms},
@@ -343,7 +456,7 @@ def main():
                      "achieved": tree_bytes_per_sim(R) * G / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0,
                      "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": (tree_bytes_per_sim(R) * G / (tree_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if tree_ms > 0 else 0.0,
-                     "kernels": "k_select (first step) + k_expand_select (expansion of step s fused with the selection of step s+1; the leaf encode happens inside k_tower) -- latency-bound: one wavefront per game"},
+                     "kernels": "k_select (first step) + k_expand_select (expansion of step s fused with the selection of step s+1; the leaf encode happens inside the tower kernel) -- latency-bound: one wavefront per game"},
     }
     if not args.no_cpu_baseline and world == 1:      # reported baselines: rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(R, INV, model, args)
@@ -357,6 +470,7 @@ def main():
     out["config"]["policy_head"] = args.policy_head
     print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

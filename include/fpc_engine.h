@@ -218,6 +218,8 @@ int fpc_tuples_count(fpc_engine *e);
 int fpc_tuples_read(fpc_engine *e, fpc_tuple *host_out, int first, int n);
 /* RCCL, driven from the C++ host (one communicator per engine = per GPU; no torch involved):
  * rank 0 makes the 128-byte id and hands it to the other ranks by whatever channel the caller has. */
+int fpc_comm_available(void);     /* 0 when librccl is bound in this process, else FPC_ECOMM (fpc_last_error(NULL) says why):
+                                   * lets every rank agree on the exchange path BEFORE any of them enters ncclCommInitRank */
 int fpc_comm_unique_id(void *id128);
 int fpc_comm_init(fpc_engine *e, const void *id128, int rank, int world);
 int fpc_comm_destroy(fpc_engine *e);
@@ -241,6 +243,8 @@ typedef struct fpc_stats {
 int fpc_stats_get(fpc_engine *e, fpc_stats *out);
 int fpc_stats_reset(fpc_engine *e);
 int fpc_set_timing(fpc_engine *e, int enabled);  /* HIP events around each stage (adds syncs) */
+const char *fpc_nn_kernel(fpc_engine *e);        /* name of the kernel that runs the residual tower for the loaded weights:
+                                                  * "k_tower" (hidden 128), "k_tower256" (hidden 256, 14x14), "k_conv3x3" (per layer), "" before fpc_load_weights */
 void *fpc_stream(fpc_engine *e);                 /* hipStream_t the engine launches on */
 
 #ifdef __cplusplus

@@ -801,7 +801,7 @@ int orc_search(orc_board *boards, int G, int R, int INV, int sims, double Cpuct,
         const float *gm = g_noise + (size_t)leaf_game[i] * g_noise_stride;
         float sg = 0.f;
         for (size_t k2 = 0; k2 < legal[i].size(); ++k2) sg = sg + gm[k2];
-        for (size_t k2 = 0; k2 < legal[i].size(); ++k2) pri[i][k2] = (1.0f - g_noise_eps) * pri[i][k2] + g_noise_eps * (gm[k2] / sg);
+        if (sg > 0.f) for (size_t k2 = 0; k2 < legal[i].size(); ++k2) pri[i][k2] = (1.0f - g_noise_eps) * pri[i][k2] + g_noise_eps * (gm[k2] / sg);
       }
     }
     for (int i = 0; i < B; ++i) {                       // mcts.py:78, node.cpp:144-154

@@ -166,3 +166,93 @@ def test_world_size_2_exchange_of_real_engine_tuples():
     for rank, recs, e, p_, z_ in got:
         assert recs == want[0], rank
         assert e == want[1] and p_ == want[2] and z_ == want[3], rank
+
+
+# ---- init_comm: every rank leaves with the same verdict, whatever fails where ----------
+class _FakeLib:
+    """the RCCL entry points of the C-ABI with a failure injected on chosen ranks"""
+
+    def __init__(self, rank, fail_available=(), fail_id=False, fail_init=()):
+        self.rank, self.fa, self.fid, self.fi = rank, fail_available, fail_id, fail_init
+        self.calls = []
+
+    def fpc_comm_available(self):
+        self.calls.append("available")
+        return -11 if self.rank in self.fa else 0
+
+    def fpc_last_error(self, _h):
+        return b"injected failure"
+
+    def fpc_comm_unique_id(self, buf):
+        self.calls.append("unique_id")
+        if self.fid:
+            return -11
+        for i in range(128):
+            buf[i] = bytes([i])
+        return 0
+
+    def fpc_comm_destroy(self, _h):
+        self.calls.append("destroy")
+        return 0
+
+
+class _FakeEngine:
+    def __init__(self, lib):
+        self.L, self.h, self.has_comm = lib, None, False
+
+    def comm_init(self, id128, rank, world):
+        self.L.calls.append("init")
+        assert bytes(id128) == bytes(range(128))
+        if rank in self.L.fi:
+            raise RuntimeError("injected ncclCommInitRank failure")
+
+
+def _comm_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    scenarios = {"all good": {}, "library missing on rank 1": {"fail_available": (1,)}, "id fails on rank 0": {"fail_id": True},
+                 "init fails on rank 1": {"fail_init": (1,)}, "init fails on rank 0": {"fail_init": (0,)}}
+    for name, kw in scenarios.items():
+        lib = _FakeLib(rank, **kw)
+        eng = _FakeEngine(lib)
+        ok, why = tuples.init_comm(eng)
+        out[name] = (ok, eng.has_comm, list(lib.calls), why)
+    # the real C-ABI on the wavefront-emulator build: RCCL does not exist there -> every rank says no, then
+    # the exchange still works through torch.distributed
+    from fpc_testlib import make_engine
+    eng = make_engine("emul", 8, 2, max_games=1, max_sims=4)
+    ok, why = tuples.init_comm(eng)
+    out["emulator build"] = (ok, getattr(eng, "has_comm", False), [], why)
+    eng.close()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_init_comm_gives_every_rank_the_same_verdict():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))     # a mismatched collective would hang here
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for name in got[0]:
+        oks = [got[r][name][0] for r in range(world)]
+        has = [got[r][name][1] for r in range(world)]
+        assert oks == has, name
+        assert len(set(oks)) == 1, (name, oks)
+        assert oks[0] == (name == "all good"), name
+    # nobody enters ncclCommInitRank unless every rank can load the library and rank 0 has an id
+    for name in ("library missing on rank 1", "id fails on rank 0"):
+        assert all("init" not in got[r][name][2] for r in range(world)), name
+    # a rank whose own init succeeded gives its communicator up when another rank's failed
+    assert got[0]["init fails on rank 1"][2][-1] == "destroy" and got[1]["init fails on rank 0"][2][-1] == "destroy"
+    assert "rank 1" in got[1]["init fails on rank 1"][3] and got[0]["init fails on rank 1"][3]
+    assert "RCCL exists only in the gfx950 build" in got[0]["emulator build"][3]

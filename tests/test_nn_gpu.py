@@ -233,14 +233,18 @@ def test_legal_only_policy_head_matches_full(R, blocks, hidden, dtype):
     # The legal-only head is NOT bit-comparable with the full head: priors agree to f32
     # rounding, so a PUCT near-tie can resolve differently.  Differing games are REPORTED above, not
     # tolerated silently: the head stays opt-in and never produces bench.py's `value`.
-    if same != G:
-        import warnings
-        warnings.warn("legal-only policy head: %d of %d games searched differently from the full head (f32 rounding)" % (G - same, G))
+    # A hard bound, so that a real regression in k_policy_gemv / k_expand_legal_select cannot pass: at
+    # most 2 of the 24 games may differ, and a game that differs must still have searched the same root
+    # children the same number of times in total (same tree size, same child set).
+    assert same >= G - 2, "legal-only policy head: %d of %d games searched differently from the full head" % (G - same, G)
+    for g in range(G):
+        assert (f2["flat"][g] == l2["flat"][g]).all() and int(f2["visits"][g].sum()) == int(l2["visits"][g].sum())
 
 
-def test_full_size_search_invariants():
-    """BASELINE configs[1] at full size -- 256 concurrent games x 400 simulations, ResNet(10,128) bf16,
-    14x14 -- where the oracle cannot follow (the CPU net alone would take hours): size-independent
+@pytest.mark.parametrize("dtype", [1, 0], ids=["fp16", "bf16"])
+def test_full_size_search_invariants(dtype):
+    """BASELINE configs[1] at full size -- 256 concurrent games x 400 simulations, ResNet(10,128), 14x14,
+    with the headline operand type (fp16) and with the one configs[1] names (bf16) -- where the oracle cannot follow (the CPU net alone would take hours): size-independent
     properties instead.  Roots are the start position advanced by 0-3 plies so the batch mixes turns
     (quirk Q6).  For every game: root N = sims + 1 and sum N_child = #children + sims - 1 (quirk Q1),
     the children are exactly the root's legal flat indices (ascending), priors are positive and sum
@@ -248,8 +252,8 @@ def test_full_size_search_invariants():
     import weights
     R, G, sims = 14, 256, 400
     m = _model(R, 10, 128, seed=0)
-    eng = make_engine("gpu", R, INV_OF[R], max_games=G, max_sims=sims, nn_dtype=0)
-    eng.load_weights(weights.export_weights(m, 0))
+    eng = make_engine("gpu", R, INV_OF[R], max_games=G, max_sims=sims, nn_dtype=dtype)
+    eng.load_weights(weights.export_weights(m, dtype))
     g = gold(R)
     st = g["start"]
     base = fpc_ffi.board_from_dict(R, st["turn"], [tuple(e) for e in st["dict"]])

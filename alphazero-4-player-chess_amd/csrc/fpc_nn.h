@@ -435,6 +435,7 @@ struct NN {
   unsigned char *stemW = nullptr;    // [9 taps][8 KiB], same order
   float *towerB = nullptr;           // [2*nblocks + 2][256] (128 used)
   bool use_tower = false;            // hidden == 128: k_tower
+  int tower_waves = getenv("FPC_TOWER_WAVES") ? atoi(getenv("FPC_TOWER_WAVES")) : 8;   // developer knob (A/B): 4 = one wave per SIMD
   bool use_tower256 = false;         // hidden == 256 on the 14x14 board: k_tower256
   void (*mark_fn)(void *, int) = nullptr;   // stage-timing hook of the engine (tag 2 = policy Linear starts)
   void *mark_ctx = nullptr;
@@ -649,26 +650,48 @@ struct NN {
       t.in16 = in16 + (size_t)guard * 32; t.Wstem = stemW; t.bstem = stem.b; t.Wt = towerW; t.bt = towerB;
       t.xfc = xfc; t.vw = vw; t.value = value_out; t.vb = vb;
       t.L = 2 * nblocks; t.P = P; t.R = dc.R; t.PP = PP; t.NR = PP - P; t.T0 = (P + 1) / 16; t.n_games = n; t.Kp = Kp; t.A_ch = dc.A_ch; t.rules = dc.rules;
+#ifdef TW_STAMPS
+      static unsigned long long *d_stamps = nullptr;
+      if (!d_stamps) { (void)hipMalloc(&d_stamps, 2 * 8 * 16 * 8); }
+      (void)hipMemsetAsync(d_stamps, 0, 2 * 8 * 16 * 8, stream);
+      t.stamps = d_stamps;
+#endif
       // row tiles of 16 grid positions per wave (two waves along M): 8x8 -> 3, 9..11 -> 5, 12..14 -> 7
       const int mt = dc.R <= 8 ? 3 : dc.R <= 11 ? 5 : 7;
       bool &attr = attr_tower[DT];
       if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 7, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 7, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 3, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 5, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 7, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 7, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 7, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 3, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
         attr = true;
       }
       if (use_tower256) {
         bool &a256 = attr_tower256[DT];
         if (!a256) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower256<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS); a256 = true; }
         hipLaunchKernelGGL((k_tower256<DT>), dim3(n), dim3(TW_THREADS), T2_LDS, stream, t);
-      } else if (mt == 3) hipLaunchKernelGGL((k_tower<DT, 3, false>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);
-      else if (mt == 5) hipLaunchKernelGGL((k_tower<DT, 5, false>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);
-      else if (P != 16) hipLaunchKernelGGL((k_tower<DT, 7, false>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);
-      else hipLaunchKernelGGL((k_tower<DT, 7, true>), dim3(n), dim3(TW_THREADS), TW_LDS, stream, t);   // 14x14: grid pitch == tile height
+      } else if (mt == 3 && tower_waves == 8) hipLaunchKernelGGL((k_tower<DT, 3, false, 8>), dim3(n), dim3(512), TW_LDS, stream, t);
+      else if (mt == 3) hipLaunchKernelGGL((k_tower<DT, 3, false, 4>), dim3(n), dim3(256), TW_LDS, stream, t);
+      else if (mt == 5) hipLaunchKernelGGL((k_tower<DT, 5, false, 4>), dim3(n), dim3(256), TW_LDS, stream, t);
+      else if (P != 16) hipLaunchKernelGGL((k_tower<DT, 7, false, 4>), dim3(n), dim3(256), TW_LDS, stream, t);
+      // 14x14 (grid pitch == tile height): two waves per SIMD, 7 x 2 tiles each
+      else if (tower_waves == 8) hipLaunchKernelGGL((k_tower<DT, 7, true, 8>), dim3(n), dim3(512), TW_LDS, stream, t);
+      else hipLaunchKernelGGL((k_tower<DT, 7, true, 4>), dim3(n), dim3(256), TW_LDS, stream, t);
       const hipError_t le = hipGetLastError();
       if (le != hipSuccess) { *err = std::string("k_tower launch failed: ") + hipGetErrorString(le); return FPC_ENODEVICE; }
+#ifdef TW_STAMPS
+      if (getenv("FPC_TW_STAMPS_FILE")) {     // diagnostic build: dump the stamps of this launch
+        unsigned long long h[2 * 8 * 16];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h, t.stamps, sizeof(h), hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(getenv("FPC_TW_STAMPS_FILE"), "w")) {
+          for (int i = 0; i < 2 * 8 * 16; ++i) fprintf(f, "%llu%c", h[i], i % 16 == 15 ? '\n' : ' ');
+          fclose(f);
+        }
+      }
+#endif
     } else if ((rc = conv(stem, in16, 32, nullptr, act[0], F, F, 0))) return rc;
     const bool fused = use_tower || use_tower256;
     for (int i = 0; i < nblocks && !fused; ++i) {

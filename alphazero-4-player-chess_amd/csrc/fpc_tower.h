@@ -110,6 +110,7 @@ struct TowerArgs {
   float vb;
   int L, P, R, PP, NR, T0, n_games, Kp, A_ch;
   int rules;                     // FPC_RULES_* (rotation / plane numbering of the fused encode)
+  unsigned long long *stamps;    // diagnostic builds only (-DTW_STAMPS): [2 taps][8 waves][16] s_memtime values of block 0; else null
 };
 
 // LDS-DMA: `PIECES` consecutive 1-KiB pieces (64 lanes x 16 B each) global -> LDS with no VGPR
@@ -133,6 +134,17 @@ __device__ __forceinline__ void tw_dma_8k(const unsigned char *gsrc_uniform, uin
       "s_mov_b32 m0, %0"
       : "=&s"(keep), "+v"(lane_off) : "s"(gsrc_uniform), "s"(lds_addr_uniform) : "memory", "scc");
 }
+__device__ __forceinline__ void tw_dma_4k(const unsigned char *gsrc_uniform, uint32_t lane_off, uint32_t lds_addr_uniform) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\ts_add_u32 m0, m0, 0x400\n\tv_add_u32 %1, 0x400, %1\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\ts_add_u32 m0, m0, 0x400\n\tv_add_u32 %1, 0x400, %1\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\ts_add_u32 m0, m0, 0x400\n\tv_add_u32 %1, 0x400, %1\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep), "+v"(lane_off) : "s"(gsrc_uniform), "s"(lds_addr_uniform) : "memory", "scc");
+}
 __device__ __forceinline__ void tw_dma_256(const unsigned char *gsrc_uniform, uint32_t lane_off, uint32_t lds_addr_uniform) {   // 64 x 4 B
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
@@ -141,8 +153,37 @@ __device__ __forceinline__ void tw_dma_256(const unsigned char *gsrc_uniform, ui
 
 // FAST: the 14x14 geometry (grid pitch 16 = tile height), where the row tiles of a wave are a constant
 // 4 KiB apart in the image and only the last one can cross the aliased bottom border.
-template <int DT, int MT, bool FAST>
-__global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
+// diagnostic builds (-DTW_STAMPS=<tap index>; tools/tower_stamps.py): s_memtime at nine points of two consecutive taps, block 0
+#ifdef TW_STAMPS
+#define TW_STAMP(GT, I)                                                                                       \
+  do {                                                                                                        \
+    if (g.stamps && blockIdx.x == 0 && ((GT) == TW_STAMPS || (GT) == TW_STAMPS + 1)) {                        \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                             \
+      if (lane == 0) g.stamps[(((GT) - TW_STAMPS) * 8 + wave) * 16 + (I)] = t_;                               \
+    }                                                                                                         \
+  } while (0)
+#else
+#define TW_STAMP(GT, I) do {} while (0)
+#endif
+// which waves of the 8-wave form issue the weight DMA: 0 = all (4 pieces each), 1 = waves 0-3, 2 = waves 4-7 (8 pieces each)
+#ifndef TW_LOADERS
+#define TW_LOADERS 0
+#endif
+
+// NW: waves per workgroup.  4 = one wave per SIMD, wave (wm, wn) owns MT row tiles x 4 column tiles (64 output
+// channels).  8 = two waves per SIMD, each with half the register file: wave (wm, wn) owns MT row tiles x 2 column
+// tiles (32 channels).  The 8-wave form pays 18 instead of 11 fragment reads per SIMD and k-step, but what one
+// wave of a SIMD cannot issue while it waits -- for an LDS-DMA piece to leave the issue port (~60 cycles), for a
+// fragment, at the epilogue's conversions -- the other one's MFMAs fill: with one wave per SIMD those costs were
+// serial with the MFMA stream.  Every output element sees the same MFMAs on the same operands in
+// the same order in both forms, so the logits are bit-identical.
+template <int DT, int MT, bool FAST, int NW>
+__global__ void __launch_bounds__(NW * 64, NW / 4) k_tower(TowerArgs g) {
+  constexpr int NT = NW * 64;                      // threads
+  constexpr int WN = NW / 2;                       // waves along the output channels
+  constexpr int CT = 8 / WN;                       // column tiles (16 channels) per wave: 4 or 2
+  constexpr int NLOAD = (NW == 8 && TW_LOADERS != 0) ? 4 : NW;   // waves that issue the weight DMA
+  constexpr int DMA_PER_WAVE = TW_TAP / NLOAD;     // bytes of a tap each of them brings in: 8 or 4 KiB
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *const img = smem + TW_IMG0;
   unsigned char *const ring = smem + TW_RING;
@@ -151,7 +192,7 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
   fpc_board *const lboard = reinterpret_cast<fpc_board *>(smem + TW_BOARD);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 15, lq = lane >> 4;
   const int game = blockIdx.x;
   const int P = g.P, NR = g.NR;
@@ -176,21 +217,23 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
   const int bq = (lq >> 1) * 256 + (lq & 1) * 128;                 // chunk-within-k-step part of a fragment address
   const int apart = (li >> 3) * 2048 + (li & 7) * 16 + bq;         // weight fragment: row li of a 16-row tile (CH = 16)
   const int apart_s = (li >> 3) * 512 + (li & 7) * 16 + bq;        // same for the stem's 4-chunk rows
-  const int cb64 = wn * 64, cb16 = wn * 16;                        // first output channel of this wave (conv layers / value conv)
+  const int cb64 = wn * (CT * 16);                                 // first output channel of this wave (conv layers)
+  const int cb16 = (wn & 1) * 16;                                  // value conv: 32 live channels, 16 per wave; NW == 8: the waves wn >= 2 sit it out
+  const bool vactive = wn < 2;
 
   // ---- zero the image, build the stem's input image, fetch the stem's weights -----------------------
-  for (int c = tid; c < (TW_IMG0 + TW_IMG) / 16; c += TW_THREADS) reinterpret_cast<t_u32x4 *>(smem)[c] = t_u32x4{0u, 0u, 0u, 0u};
+  for (int c = tid; c < (TW_IMG0 + TW_IMG) / 16; c += NT) reinterpret_cast<t_u32x4 *>(smem)[c] = t_u32x4{0u, 0u, 0u, 0u};
   unsigned char *const enc = smem + TW_ENC;
   const int enc_bytes = ((NR + 7) >> 3) * 512;
-  for (int c = tid; c < enc_bytes / 16; c += TW_THREADS) reinterpret_cast<t_u32x4 *>(enc)[c] = t_u32x4{0u, 0u, 0u, 0u};
+  for (int c = tid; c < enc_bytes / 16; c += NT) reinterpret_cast<t_u32x4 *>(enc)[c] = t_u32x4{0u, 0u, 0u, 0u};
   {  // stem weights: 72 KiB by plain 16-byte copies (once per launch)
     const t_u32x4 *src = reinterpret_cast<const t_u32x4 *>(g.Wstem);
     t_u32x4 *dst = reinterpret_cast<t_u32x4 *>(ring);
-    for (int c = tid; c < 9 * TW_STEM_TAP / 16; c += TW_THREADS) dst[c] = src[c];
+    for (int c = tid; c < 9 * TW_STEM_TAP / 16; c += NT) dst[c] = src[c];
   }
-  t_f32x4 bst[4];
+  t_f32x4 bst[CT];
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct) bst[ct] = *reinterpret_cast<const t_f32x4 *>(g.bstem + cb64 + ct * 16 + 4 * lq);
+  for (int ct = 0; ct < CT; ++ct) bst[ct] = *reinterpret_cast<const t_f32x4 *>(g.bstem + cb64 + ct * 16 + 4 * lq);
   __syncthreads();
   if (g.boards) {
     constexpr int WPB = (int)(sizeof(fpc_board) / 4);
@@ -200,7 +243,7 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
     // GetEncodedStates: plane = 6*((colour - turn) & 3) + type - 1, -1 wrapping to 23 (Q7); the whole
     // batch is rotated by the turn of the first live leaf (Q6) -- unless the non-strict rules say otherwise
     if (g.rules & FPC_RULES_ROTATION) rot_k = lboard->turn;
-    for (int r = tid; r < g.PP; r += TW_THREADS) {
+    for (int r = tid; r < g.PP; r += NT) {
       const int pi = r / P, pj = r - pi * P;
       if (pi < 1 || pi > g.R || pj < 1 || pj > g.R) continue;
       const uint8_t p = lboard->sq[rot90_src(g.R, rot_k, pi - 1, pj - 1)];
@@ -210,7 +253,7 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
     }
   } else {
     const uint16_t *src = g.in16 + (size_t)game * g.PP * 32;
-    for (int c = tid; c < NR * 4; c += TW_THREADS) {
+    for (int c = tid; c < NR * 4; c += NT) {
       const int r = c >> 2, j = c & 3;
       *reinterpret_cast<t_u32x4 *>(enc + tw_lay(4, r, j)) = *reinterpret_cast<const t_u32x4 *>(src + (size_t)r * 32 + j * 8);
     }
@@ -219,8 +262,8 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
 
   // Accumulators are never zeroed: the first MFMA of every layer takes the layer's bias as C
   // (a zero-initialised accumulator carried into the tap loop makes hipcc rotate 100+ registers per tap).
-  t_f32x4 acc[MT][4];
-  t_u32x2 res[MT][4];           // residual x_l of this lane's outputs, packed 16-bit channel pairs
+  t_f32x4 acc[MT][CT];
+  t_u32x2 res[MT][CT];           // residual x_l of this lane's outputs, packed 16-bit channel pairs
 
   // image row of this lane for row tile mt under a tap shift, bottom border aliased onto the top one
   auto brow = [&](int mt, int shift) -> int {
@@ -234,9 +277,9 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const int shift = (tap / 3 - 1) * P + (tap % 3 - 1);
-    t_u32x4 fa[4], fb[MT];
+    t_u32x4 fa[CT], fb[MT];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < CT; ++ct)
       fa[ct] = *reinterpret_cast<const t_u32x4 *>(ring + tap * TW_STEM_TAP + (cb64 + ct * 16) * 64 + apart_s);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -246,20 +289,25 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) acc[mt][ct] = M16<DT>::mfma(fa[ct], fb[mt], tap == 0 ? bst[ct] : acc[mt][ct]);
+      for (int ct = 0; ct < CT; ++ct) acc[mt][ct] = M16<DT>::mfma(fa[ct], fb[mt], tap == 0 ? bst[ct] : acc[mt][ct]);
   }
   __syncthreads();               // every wave is done with the stem's weights and input image
 
   // ---- weight ring ------------------------------------------------------------------------------------
   const int total = (g.L + 2) * 9;
   const uint32_t dma_lane = (uint32_t)lane * 16u;
-  auto issue_tap = [&](int gt) {   // tap gt -> ring slot gt % 3 (8 x 1 KiB per wave); first tap of a layer: + its biases
-    tw_dma_8k(g.Wt + (size_t)gt * TW_TAP + wave * 8192, dma_lane,
-              (uint32_t)__builtin_amdgcn_readfirstlane(TW_RING + (gt % 3) * TW_TAP + wave * 8192));   // smem starts at LDS byte 0
-    if (gt % 9 == 0) {
+  const bool loader = NLOAD == NW || (TW_LOADERS == 1 ? wave < 4 : wave >= 4);
+  const int lw = wave & (NLOAD - 1);               // index among the loader waves
+  auto issue_tap = [&](int gt) {   // tap gt -> ring slot gt % 3 (32 / NLOAD pieces of 1 KiB per loader wave); first tap of a layer: + its biases
+    if (!loader) return;           // wave-uniform
+    const unsigned char *src = g.Wt + (size_t)gt * TW_TAP + lw * DMA_PER_WAVE;
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(TW_RING + (gt % 3) * TW_TAP + lw * DMA_PER_WAVE);   // smem starts at LDS byte 0
+    if (DMA_PER_WAVE == 8192) tw_dma_8k(src, dma_lane, dst);
+    else tw_dma_4k(src, dma_lane, dst);
+    if (gt % 9 == 0 && lw < 4 && (NLOAD < NW || wave < 4)) {
       const int l = gt / 9;
-      tw_dma_256(reinterpret_cast<const unsigned char *>(g.bt + (size_t)l * 256 + wave * 64), (uint32_t)lane * 4u,
-                 (uint32_t)__builtin_amdgcn_readfirstlane(TW_BIAS + ((l & 1) * 256 + wave * 64) * 4));
+      tw_dma_256(reinterpret_cast<const unsigned char *>(g.bt + (size_t)l * 256 + lw * 64), (uint32_t)lane * 4u,
+                 (uint32_t)__builtin_amdgcn_readfirstlane(TW_BIAS + ((l & 1) * 256 + lw * 64) * 4));
     }
   };
   issue_tap(0);
@@ -269,14 +317,14 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
   // written IN PLACE into the image at interior squares (4 consecutive channels = one 8-byte write; the
   // other lanes write to a dummy strip, no branch)
   unsigned char *const dummy = smem + TW_DUMMY + lane * 8;
-  unsigned char *const wbase = img + (rbase >> 3) * 2048 + (rbase & 7) * 16 + wn * 1024 + (lane >> 5) * 128 + ((lane >> 4) & 1) * 8;
+  unsigned char *const wbase = img + (rbase >> 3) * 2048 + (rbase & 7) * 16 + wn * (CT * 256) + (lane >> 5) * 128 + ((lane >> 4) & 1) * 8;
   auto epilogue = [&](auto res_c) {
     constexpr int RES = decltype(res_c)::value;      // 0: plain; 1: keep as residual (stem); 2: add the residual, keep
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       unsigned char *dst = ((inmask >> mt) & 1u) ? wbase + mt * 4096 : dummy;
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
+      for (int ct = 0; ct < CT; ++ct) {
         t_f32x4 v = acc[mt][ct];
         if (RES == 2) {
           v[0] += M16<DT>::lo(res[mt][ct][0]); v[1] += M16<DT>::hi(res[mt][ct][0]);
@@ -302,7 +350,7 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
   // unconditional and lands in a statically named register set.  The k-step loop is rotated by one:
   // a layer opens with (tap 0, k-step 0) on C = bias, and the tap loop body is k-steps 1, 2, 3 of its
   // tap followed by k-step 0 of the next one.
-  t_u32x4 fa[2][4], fb[2][MT];
+  t_u32x4 fa[2][CT], fb[2][MT];
   int gt = 0;                                      // running tap index over all layers (ring slot = gt % 3)
   const unsigned char *wslot;                      // this wave's weight rows in the current tap's ring slot
   const unsigned char *bbase;                      // FAST: this lane's image row in its first row tile under the current shift
@@ -339,15 +387,15 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
     constexpr bool BIAS = decltype(bias_c)::value != 0;
     constexpr int N = B ^ 1;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) fa[N][ct] = *reinterpret_cast<const t_u32x4 *>(wslot + ct * 4096 + KSN * 512);
+    for (int ct = 0; ct < CT; ++ct) fa[N][ct] = *reinterpret_cast<const t_u32x4 *>(wslot + ct * 4096 + KSN * 512);
     fb[N][0] = *reinterpret_cast<const t_u32x4 *>(bptr(0) + KSN * 512);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if (MODE == 0) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[mt][ct] = M16<DT>::mfma(fa[B][ct], fb[B][mt], BIAS ? b4[ct] : acc[mt][ct]);
-      } else {
+        for (int ct = 0; ct < CT; ++ct) acc[mt][ct] = M16<DT>::mfma(fa[B][ct], fb[B][mt], BIAS ? b4[ct] : acc[mt][ct]);
+      } else if (NW == 4 || vactive) {             // wave-uniform
         acc[mt][0] = M16<DT>::mfma(fa[B][0], fb[B][mt], BIAS ? b4[0] : acc[mt][0]);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -367,33 +415,42 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
   // (load_b0 after it).
   auto run_layer = [&](auto mode_c, const int layer, const int cb, const int cb_next) {
     constexpr int MODE = decltype(mode_c)::value;
-    t_f32x4 b4[4];
+    t_f32x4 b4[CT];
     {
       const float *bl = biasbuf + (layer & 1) * 256 + cb + 4 * lq;
 #pragma unroll
-      for (int ct = 0; ct < (MODE == 0 ? 4 : 1); ++ct) b4[ct] = *reinterpret_cast<const t_f32x4 *>(bl + ct * 16);
+      for (int ct = 0; ct < (MODE == 0 ? CT : 1); ++ct) b4[ct] = *reinterpret_cast<const t_f32x4 *>(bl + ct * 16);
     }
     kstep(mode_c, c0, c1, c1, b4);                 // (tap 0, k-step 0), C = bias
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
+      TW_STAMP(gt, 0);
       kstep(mode_c, c1, c2, c0, b4);               // k-step 1
+      TW_STAMP(gt, 1);
       kstep(mode_c, c0, c3, c0, b4);               // k-step 2
+      TW_STAMP(gt, 2);
       // the next tap's weights: every wave's DMA pieces have landed, and nobody still reads the slot that
       // tap gt + 2 is about to overwrite (all waves are past tap gt - 1).  Also: all fragment reads of
       // this tap are complete, so after tap 8 the epilogue may rewrite the image in place.
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      TW_STAMP(gt, 3);
       __syncthreads();
+      TW_STAMP(gt, 4);
       if (gt + 2 < total) issue_tap(gt + 2);
+      TW_STAMP(gt, 5);
       ++gt;
       set_tap(tap == 8 ? 0 : tap + 1, tap == 8 ? cb_next : cb);
+      TW_STAMP(gt - 1, 6);
       kstep(mode_c, c1, c0, c0, b4);               // k-step 3, reading (next tap, k-step 0)
+      TW_STAMP(gt - 1, 7);
       if (tap < 8) kstep(mode_c, c0, c1, c0, b4);  // (next tap, k-step 0)
+      TW_STAMP(gt - 1, 8);
     }
   };
 
   set_tap(0, cb64);
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct) fa[0][ct] = *reinterpret_cast<const t_u32x4 *>(wslot + ct * 4096);
+  for (int ct = 0; ct < CT; ++ct) fa[0][ct] = *reinterpret_cast<const t_u32x4 *>(wslot + ct * 4096);
   load_b0();
   const int nblocks = g.L / 2;
 #pragma unroll 1
@@ -415,7 +472,7 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
     for (int mt = 0; mt < MT; ++mt) {
       const int r = rbase + 16 * mt;
       const int pi = r / P, pj = r - pi * P;
-      const bool in = (inmask >> mt) & 1u;
+      const bool in = ((inmask >> mt) & 1u) && (NW == 4 || vactive);
       const int qp = in ? (pi - 1) * g.R + (pj - 1) : 0;
       const t_f32x4 w4 = *reinterpret_cast<const t_f32x4 *>(g.vw + qp * 32 + cb16 + 4 * lq);
 #pragma unroll
@@ -434,7 +491,7 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
   // ---- heads: policy-conv rows -> Linear input (position-major), value -> tanh ---------------------------
   {
     const int cpr = g.A_ch / 8;                     // 16-byte chunks per position
-    for (int c = tid; c < g.PP * 16; c += TW_THREADS) {
+    for (int c = tid; c < g.PP * 16; c += NT) {
       const int r = c >> 4, j = c & 15;
       if (j >= cpr) continue;
       const int pi = r / P, pj = r - pi * P;
@@ -447,7 +504,8 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower(TowerArgs g) {
   for (int off = 32; off >= 1; off >>= 1) vpart += __shfl_xor(vpart, off);
   if (lane == 0) vred[wave] = vpart;
   __syncthreads();
-  if (tid == 0) g.value[game] = tanhf(g.vb + ((vred[0] + vred[1]) + (vred[2] + vred[3])));
+  // partials in the 4-wave order (wm, wn & 1); NW == 8: the waves with wn >= 2 hold zero and are not read
+  if (tid == 0) g.value[game] = tanhf(g.vb + ((vred[0] + vred[1]) + (vred[WN] + vred[WN + 1])));
 }
 
 // weights [taps][128 rows][cin] 16-bit row-major -> per tap the LDS image (tw_lay with cin/8 chunks per row)

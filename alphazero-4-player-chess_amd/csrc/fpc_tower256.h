@@ -28,18 +28,7 @@ constexpr int T2_RING = T2_IMG0 + T2_IMG;        // 126976: 2 slabs
 constexpr int T2_LDS = T2_RING + 2 * T2_SLAB;    // 159744
 constexpr int T2_KS = 8;                         // k-steps per tap (256 / 32)
 
-// 4 consecutive 1-KiB LDS-DMA pieces (see tw_dma_8k)
-__device__ __forceinline__ void tw_dma_4k(const unsigned char *gsrc_uniform, uint32_t lane_off, uint32_t lds_addr_uniform) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\ts_add_u32 m0, m0, 0x400\n\tv_add_u32 %1, 0x400, %1\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\ts_add_u32 m0, m0, 0x400\n\tv_add_u32 %1, 0x400, %1\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\ts_add_u32 m0, m0, 0x400\n\tv_add_u32 %1, 0x400, %1\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep), "+v"(lane_off) : "s"(gsrc_uniform), "s"(lds_addr_uniform) : "memory", "scc");
-}
+// tw_dma_4k (4 consecutive 1-KiB LDS-DMA pieces): fpc_tower.h
 
 // TowerArgs as for k_tower, with: Wstem = 9 slabs, Wt = (L + 2) * 72 slabs, bt = [L + 2][256].  14x14 only.
 template <int DT>

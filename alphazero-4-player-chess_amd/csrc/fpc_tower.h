@@ -165,9 +165,16 @@ __device__ __forceinline__ void tw_dma_256(const unsigned char *gsrc_uniform, ui
 #else
 #define TW_STAMP(GT, I) do {} while (0)
 #endif
-// which waves of the 8-wave form issue the weight DMA: 0 = all (4 pieces each), 1 = waves 0-3, 2 = waves 4-7 (8 pieces each)
+// Which waves of the 8-wave form issue the weight DMA: 0 = all (4 pieces each), 1 = waves 0-3, 2 = waves 4-7
+// (8 pieces each).  Same-box A/B (bench.py, k_tower per launch): 0.2988 / 0.2840 / 0.2994 ms.  The two waves of
+// a SIMD are w and w + 4; when only the older one of each pair carries the ~520 issue cycles of a tap's 32 pieces
+// (the CU's vector-memory path takes 1 KiB per 16 cycles, s_memtime stamps: tools/tower_stamps.py), the younger
+// one has the SIMD's matrix pipe to itself meanwhile instead of queueing its own pieces behind them.
+// Also measured and NOT kept (all same-box, all slower or equal): the stream two taps ahead (counted vmcnt; +1.5 %),
+// its pieces spread between the MFMAs of the k-steps (+6...+10 %: a piece holds its wave ~64 cycles wherever it
+// stands), static s_setprio for either half (0...+3 %), uneven row-tile halves 8/6, 9/5, 6/8 (+1...+10 %, spills).
 #ifndef TW_LOADERS
-#define TW_LOADERS 0
+#define TW_LOADERS 1
 #endif
 
 // NW: waves per workgroup.  4 = one wave per SIMD, wave (wm, wn) owns MT row tiles x 4 column tiles (64 output

@@ -31,7 +31,7 @@ knob, a, b = sys.argv[1:4]
 shape = sys.argv[4:7] if len(sys.argv) >= 7 else ["14", "10", "128"]
 outs = []
 for v in (a, b):
-    out = "/tmp/same_logits_%s_%s.npz" % (knob, v)
+    out = "/tmp/same_logits_%s_%s.npz" % (knob, os.path.basename(v))
     subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", *shape, out], env=dict(os.environ, **{knob: v}))
     outs.append(np.load(out))
 ok = True

@@ -56,6 +56,15 @@ __device__ __forceinline__ void fc_dma(const void *gsrc_uniform, uint32_t lane_o
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_addr_uniform) : "memory");
 }
+// two consecutive pieces (source and destination both advance by 1 KiB: the instruction's immediate moves BOTH
+// addresses, tools/micro/dma_imm_check.cpp) behind ONE write of M0: an s_mov to M0 waits for the wave's LDS reads
+// in flight (~20 cycles beside a fragment stream, tools/micro/dma_stagger.cpp), the piece itself costs ~6
+__device__ __forceinline__ void fc_dma2_nt(const void *gsrc_uniform, uint32_t lane_off, uint32_t lds_addr_uniform) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:1024 nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_addr_uniform) : "memory");
+}
 // the same with the non-temporal hint: for bytes that are read once per launch (the weight stream)
 __device__ __forceinline__ void fc_dma_nt(const void *gsrc_uniform, uint32_t lane_off, uint32_t lds_addr_uniform) {
   uint32_t keep;
@@ -120,8 +129,7 @@ __global__ void __launch_bounds__(FC_THREADS, 1) k_fc(FcArgs g) {
     const int sc = s < S ? s : S - 1;
     const unsigned char *src = wbase + (long)(4 * sc + ks) * wkstep;
     const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(lds_w + ((s & 1) * 8 + ks * 2) * 1024);
-    fc_dma_nt(src, wlane, dst);
-    fc_dma_nt(src + 1024, wlane, dst + 1024);
+    fc_dma2_nt(src, wlane, dst);
   };
   auto xfrag = [&](int b, int t, const unsigned char *ab, int ks) {
     xf[b][t] = *reinterpret_cast<const u32x4_t *>(ab + lds_off<64>(t * 32 + (lane & 31), ks * 2 + (lane >> 5)));

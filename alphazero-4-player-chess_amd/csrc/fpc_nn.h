@@ -566,7 +566,7 @@ struct NN {
       // k_tower streams every tap as one 32 KiB block already laid out as its LDS image (fpc_tower.h);
       // layers: c1[0], c2[0], ..., then the value conv and the policy conv
       const int layers = 2 * nblocks + 2;
-      if ((rc = dmalloc(&towerW, (size_t)layers * 9 * TW_TAP, err)) || (rc = dmalloc(&stemW, (size_t)9 * TW_STEM_TAP, err)) ||
+      if ((rc = dmalloc(&towerW, (size_t)(layers * 9 + 3) * TW_TAP, err)) || (rc = dmalloc(&stemW, (size_t)9 * TW_STEM_TAP, err)) ||
           (rc = dmalloc(&towerB, (size_t)layers * 256, err))) return rc;
       auto prep = [&](const ConvW &cw, int layer) {
         hipLaunchKernelGGL(k_tower_prep, dim3((9 * 128 * 16 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)cw.w,

@@ -145,6 +145,17 @@ __device__ __forceinline__ void tw_dma_4k(const unsigned char *gsrc_uniform, uin
       "s_mov_b32 m0, %0"
       : "=&s"(keep), "+v"(lane_off) : "s"(gsrc_uniform), "s"(lds_addr_uniform) : "memory", "scc");
 }
+// one 1-KiB piece at immediate offset OFF from the wave's stream base: M0 (set once per tap by tw_set_m0) + OFF is
+// the LDS destination and gsrc + OFF the source -- the instruction's immediate moves BOTH addresses
+// (tools/micro/dma_imm_check.cpp).  No M0 write here on purpose: an s_mov to M0 waits for the wave's LDS reads
+// in flight (~20 cycles each beside a fragment stream, tools/micro/dma_stagger.cpp), the piece itself costs ~6.
+template <int OFF>
+__device__ __forceinline__ void tw_dma_piece(const unsigned char *gsrc_uniform, uint32_t lane_off) {
+  asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(lane_off), "s"(gsrc_uniform), "i"(OFF) : "memory");
+}
+__device__ __forceinline__ void tw_set_m0(uint32_t lds_addr_uniform) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(lds_addr_uniform) : "memory");
+}
 __device__ __forceinline__ void tw_dma_256(const unsigned char *gsrc_uniform, uint32_t lane_off, uint32_t lds_addr_uniform) {   // 64 x 4 B
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
@@ -165,14 +176,23 @@ __device__ __forceinline__ void tw_dma_256(const unsigned char *gsrc_uniform, ui
 #else
 #define TW_STAMP(GT, I) do {} while (0)
 #endif
-// Which waves of the 8-wave form issue the weight DMA: 0 = all (4 pieces each), 1 = waves 0-3, 2 = waves 4-7
-// (8 pieces each).  Same-box A/B (bench.py, k_tower per launch): 0.2988 / 0.2840 / 0.2994 ms.  The two waves of
-// a SIMD are w and w + 4; when only the older one of each pair carries the ~520 issue cycles of a tap's 32 pieces
-// (the CU's vector-memory path takes 1 KiB per 16 cycles, s_memtime stamps: tools/tower_stamps.py), the younger
-// one has the SIMD's matrix pipe to itself meanwhile instead of queueing its own pieces behind them.
-// Also measured and NOT kept (all same-box, all slower or equal): the stream two taps ahead (counted vmcnt; +1.5 %),
-// its pieces spread between the MFMAs of the k-steps (+6...+10 %: a piece holds its wave ~64 cycles wherever it
-// stands), static s_setprio for either half (0...+3 %), uneven row-tile halves 8/6, 9/5, 6/8 (+1...+10 %, spills).
+// The weight stream (32 KiB per tap = 32 LDS-DMA pieces of 1 KiB per CU).
+// TW_AHEAD 1 (round 2): the tap two ahead... of the tap being read is issued as ONE burst behind each tap barrier;
+//   the CU's vector-memory path takes 1 KiB per 16 cycles, so the burst holds its waves ~520 cycles per tap
+//   (s_memtime stamps, tools/tower_stamps.py).
+// TW_AHEAD 2: the stream runs one tap further ahead (the slot of the tap whose last fragments went into registers
+//   before the barrier is free) and its pieces go out BETWEEN the MFMAs of the four k-steps behind the barrier,
+//   2 * LOAD... per k-step.  What makes that cheap is that M0 is written once per tap (right behind the barrier,
+//   no LDS read in flight) and every piece addresses its destination through the instruction's immediate:
+//   an s_mov to M0 in the middle of the fragment stream waits for the reads in flight (~20 cycles; with it the
+//   spread stream was 6-10 % SLOWER than the burst).  The wait in front of a barrier leaves exactly the youngest
+//   tap's pieces in flight (`s_waitcnt vmcnt` retires in issue order).  The stream runs 3 taps past the end of the
+//   weights (padding allocated by the host) so that no k-step carries a branch.
+// TW_LOADERS (8-wave form): 0 = every wave carries 1 piece per k-step, 1 = waves 0-3 carry 2, waves 4-7 none
+//   (code specialised per half: no branch in the k-steps).
+#ifndef TW_AHEAD
+#define TW_AHEAD 2
+#endif
 #ifndef TW_LOADERS
 #define TW_LOADERS 1
 #endif
@@ -184,13 +204,15 @@ __device__ __forceinline__ void tw_dma_256(const unsigned char *gsrc_uniform, ui
 // fragment, at the epilogue's conversions -- the other one's MFMAs fill: with one wave per SIMD those costs were
 // serial with the MFMA stream.  Every output element sees the same MFMAs on the same operands in
 // the same order in both forms, so the logits are bit-identical.
-template <int DT, int MT, bool FAST, int NW>
-__global__ void __launch_bounds__(NW * 64, NW / 4) k_tower(TowerArgs g) {
+// LOAD: weight-DMA pieces this wave carries per k-step (0, 1 or 2), i.e. 4 * LOAD KiB of every tap
+template <int DT, int MT, bool FAST, int NW, int LOAD>
+__device__ __forceinline__ void tw_body(const TowerArgs &g) {
   constexpr int NT = NW * 64;                      // threads
   constexpr int WN = NW / 2;                       // waves along the output channels
   constexpr int CT = 8 / WN;                       // column tiles (16 channels) per wave: 4 or 2
-  constexpr int NLOAD = (NW == 8 && TW_LOADERS != 0) ? 4 : NW;   // waves that issue the weight DMA
-  constexpr int DMA_PER_WAVE = TW_TAP / NLOAD;     // bytes of a tap each of them brings in: 8 or 4 KiB
+  constexpr int PIECES = 4 * LOAD;                 // 1-KiB pieces of a tap this wave brings in
+  constexpr int DMA_PER_WAVE = PIECES * 1024;
+  constexpr int MID = PIECES == 8 ? 4096 : 0;      // the stream base sits in the middle of an 8-KiB share (immediates reach -4096 .. 4095)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *const img = smem + TW_IMG0;
   unsigned char *const ring = smem + TW_RING;
@@ -303,22 +325,42 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tower(TowerArgs g) {
   // ---- weight ring ------------------------------------------------------------------------------------
   const int total = (g.L + 2) * 9;
   const uint32_t dma_lane = (uint32_t)lane * 16u;
-  const bool loader = NLOAD == NW || (TW_LOADERS == 1 ? wave < 4 : wave >= 4);
-  const int lw = wave & (NLOAD - 1);               // index among the loader waves
-  auto issue_tap = [&](int gt) {   // tap gt -> ring slot gt % 3 (32 / NLOAD pieces of 1 KiB per loader wave); first tap of a layer: + its biases
-    if (!loader) return;           // wave-uniform
-    const unsigned char *src = g.Wt + (size_t)gt * TW_TAP + lw * DMA_PER_WAVE;
-    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(TW_RING + (gt % 3) * TW_TAP + lw * DMA_PER_WAVE);   // smem starts at LDS byte 0
-    if (DMA_PER_WAVE == 8192) tw_dma_8k(src, dma_lane, dst);
-    else tw_dma_4k(src, dma_lane, dst);
-    if (gt % 9 == 0 && lw < 4 && (NLOAD < NW || wave < 4)) {
-      const int l = gt / 9;
-      tw_dma_256(reinterpret_cast<const unsigned char *>(g.bt + (size_t)l * 256 + lw * 64), (uint32_t)lane * 4u,
-                 (uint32_t)__builtin_amdgcn_readfirstlane(TW_BIAS + ((l & 1) * 256 + lw * 64) * 4));
+  const int lw = LOAD == 2 ? (wave & 3) : wave;    // index among the waves that carry the stream
+  auto issue_bias = [&](int T) {                   // with a layer's first tap: its biases (waves 0-3)
+    if (T % 9 == 0 && T < total && wave < 4) {
+      const int l = T / 9;
+      tw_dma_256(reinterpret_cast<const unsigned char *>(g.bt + (size_t)l * 256 + wave * 64), (uint32_t)lane * 4u,
+                 (uint32_t)__builtin_amdgcn_readfirstlane(TW_BIAS + ((l & 1) * 256 + wave * 64) * 4));
     }
+  };
+  auto issue_tap = [&](int T) {   // the whole tap T -> ring slot T % 3 in one burst
+    issue_bias(T);
+    if (LOAD == 0) return;
+    const unsigned char *src = g.Wt + (size_t)T * TW_TAP + lw * DMA_PER_WAVE;
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(TW_RING + (T % 3) * TW_TAP + lw * DMA_PER_WAVE);   // smem starts at LDS byte 0
+    if (PIECES == 8) tw_dma_8k(src, dma_lane, dst);
+    else tw_dma_4k(src, dma_lane, dst);
+  };
+  // TW_AHEAD 2: the stream.  open_tap(T) right behind a tap barrier (no LDS read in flight): M0 and the source
+  // base of tap T; piece<I>() anywhere after that.
+  const unsigned char *dsrc = g.Wt;
+  auto open_tap = [&](int T) {
+    issue_bias(T);                                 // saves / restores M0 itself, so: before M0 is set
+    if (LOAD == 0) return;
+    dsrc = g.Wt + (size_t)T * TW_TAP + lw * DMA_PER_WAVE + MID;
+    tw_set_m0((uint32_t)__builtin_amdgcn_readfirstlane(TW_RING + (T % 3) * TW_TAP + lw * DMA_PER_WAVE + MID));
+  };
+  auto piece = [&](auto i_c) {
+    constexpr int I = decltype(i_c)::value;
+    if (LOAD != 0) tw_dma_piece<I * 1024 - MID>(dsrc, dma_lane);
   };
   issue_tap(0);
   issue_tap(1);
+  if (TW_AHEAD == 2) {                             // first quarter of tap 2; the k-steps carry on from there
+    open_tap(2);
+    piece(std::integral_constant<int, 0>{});
+    if (LOAD == 2) piece(std::integral_constant<int, 1>{});
+  }
 
   // epilogue: the accumulators hold conv + bias; (+ residual, f32); 16-bit; ReLU on the packed pairs;
   // written IN PLACE into the image at interior squares (4 consecutive channels = one 8-byte write; the
@@ -349,8 +391,9 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tower(TowerArgs g) {
   const std::integral_constant<int, 2> c2{};
   const std::integral_constant<int, 3> c3{};
   epilogue(c1);                  // stem: x_0 = relu(conv + b)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();               // x_0 complete, taps 0 and 1 (and layer 0's biases) landed
+  if (TW_AHEAD == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES + LOAD) : "memory");   // tap 1 and the first quarter of tap 2 stay in flight
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();               // x_0 complete, tap 0 and layer 0's biases landed
 
   // ---- the tower: L residual convs + value conv + policy conv, 9 taps x 4 k-steps each -------------
   // Fragments are double-buffered one k-step ahead of the MFMAs that consume them; every load below is
@@ -389,10 +432,12 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tower(TowerArgs g) {
   // read down to just in front of its first use and expose the LDS latency.
   // MODE 0: 64 output channels per wave (4 column tiles); MODE 1 (value conv, 32 live channels): 16 per wave.
   // BIAS: this is the layer's first k-step: C = the layer's bias instead of the accumulators.
-  auto kstep = [&](auto mode_c, auto buf_c, auto ksn_c, auto bias_c, const t_f32x4 *b4) {
+  // Q: the k-step's position behind the tap barrier (k-step 3 = 0, next tap's k-steps 0, 1, 2 = 1, 2, 3): with
+  // TW_AHEAD 2 it carries pieces LOAD * Q ... of the open tap between its MFMAs.
+  auto kstep = [&](auto mode_c, auto buf_c, auto ksn_c, auto bias_c, const t_f32x4 *b4, auto q_c) {
     constexpr int MODE = decltype(mode_c)::value, B = decltype(buf_c)::value, KSN = decltype(ksn_c)::value;
     constexpr bool BIAS = decltype(bias_c)::value != 0;
-    constexpr int N = B ^ 1;
+    constexpr int N = B ^ 1, Q = decltype(q_c)::value;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) fa[N][ct] = *reinterpret_cast<const t_u32x4 *>(wslot + ct * 4096 + KSN * 512);
     fb[N][0] = *reinterpret_cast<const t_u32x4 *>(bptr(0) + KSN * 512);
@@ -408,6 +453,11 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tower(TowerArgs g) {
       __builtin_amdgcn_sched_barrier(0);
       if (mt + 1 < MT) {
         fb[N][mt + 1] = *reinterpret_cast<const t_u32x4 *>(bptr(mt + 1) + KSN * 512);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (TW_AHEAD == 2 && LOAD != 0) {
+        if (mt == (LOAD == 2 ? MT / 3 : MT / 2)) piece(std::integral_constant<int, LOAD * Q>{});
+        if (LOAD == 2 && mt == (2 * MT) / 3) piece(std::integral_constant<int, LOAD * Q + 1>{});
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -428,29 +478,32 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tower(TowerArgs g) {
 #pragma unroll
       for (int ct = 0; ct < (MODE == 0 ? CT : 1); ++ct) b4[ct] = *reinterpret_cast<const t_f32x4 *>(bl + ct * 16);
     }
-    kstep(mode_c, c0, c1, c1, b4);                 // (tap 0, k-step 0), C = bias
+    kstep(mode_c, c0, c1, c1, b4, c1);             // (tap 0, k-step 0), C = bias
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
       TW_STAMP(gt, 0);
-      kstep(mode_c, c1, c2, c0, b4);               // k-step 1
+      kstep(mode_c, c1, c2, c0, b4, c2);           // k-step 1
       TW_STAMP(gt, 1);
-      kstep(mode_c, c0, c3, c0, b4);               // k-step 2
+      kstep(mode_c, c0, c3, c0, b4, c3);           // k-step 2
       TW_STAMP(gt, 2);
-      // the next tap's weights: every wave's DMA pieces have landed, and nobody still reads the slot that
-      // tap gt + 2 is about to overwrite (all waves are past tap gt - 1).  Also: all fragment reads of
-      // this tap are complete, so after tap 8 the epilogue may rewrite the image in place.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // tap gt + 1's weights: every wave's pieces of it have landed (TW_AHEAD 2: tap gt + 2's stay in flight),
+      // and nobody reads slot gt % 3 any more -- the fragments of this tap's last k-step are in registers -- so
+      // (TW_AHEAD 2) tap gt + 3 goes there.  Also: all fragment reads of this tap are complete, so after tap 8
+      // the epilogue may rewrite the image in place.
+      if (TW_AHEAD == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       TW_STAMP(gt, 3);
       __syncthreads();
       TW_STAMP(gt, 4);
-      if (gt + 2 < total) issue_tap(gt + 2);
+      if (TW_AHEAD == 2) open_tap(gt + 3);
+      else if (gt + 2 < total) issue_tap(gt + 2);
       TW_STAMP(gt, 5);
       ++gt;
       set_tap(tap == 8 ? 0 : tap + 1, tap == 8 ? cb_next : cb);
       TW_STAMP(gt - 1, 6);
-      kstep(mode_c, c1, c0, c0, b4);               // k-step 3, reading (next tap, k-step 0)
+      kstep(mode_c, c1, c0, c0, b4, c0);           // k-step 3, reading (next tap, k-step 0)
       TW_STAMP(gt - 1, 7);
-      if (tap < 8) kstep(mode_c, c0, c1, c0, b4);  // (next tap, k-step 0)
+      if (tap < 8) kstep(mode_c, c0, c1, c0, b4, c1);  // (next tap, k-step 0)
       TW_STAMP(gt - 1, 8);
     }
   };
@@ -513,6 +566,19 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tower(TowerArgs g) {
   __syncthreads();
   // partials in the 4-wave order (wm, wn & 1); NW == 8: the waves with wn >= 2 hold zero and are not read
   if (tid == 0) g.value[game] = tanhf(g.vb + ((vred[0] + vred[1]) + (vred[WN] + vred[WN + 1])));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stream's tail (pieces past the last tap): nothing may still target LDS at exit
+}
+
+// The two wave halves of the 8-wave form may carry different shares of the weight stream (TW_LOADERS); they run the
+// same sequence of barriers.
+template <int DT, int MT, bool FAST, int NW>
+__global__ void __launch_bounds__(NW * 64, NW / 4) k_tower(TowerArgs g) {
+  if (NW == 8 && TW_LOADERS == 1) {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) tw_body<DT, MT, FAST, NW, 2>(g);
+    else tw_body<DT, MT, FAST, NW, 0>(g);
+  } else {
+    tw_body<DT, MT, FAST, NW, NW == 4 ? 2 : 1>(g);
+  }
 }
 
 // weights [taps][128 rows][cin] 16-bit row-major -> per tap the LDS image (tw_lay with cin/8 chunks per row)

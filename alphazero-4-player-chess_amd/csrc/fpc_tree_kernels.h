@@ -86,7 +86,7 @@ struct __attribute__((aligned(16))) WaveLds {
   uint16_t poff[FPC_MAX_PL + 1];       // first pseudo-move of each piece-list entry
   uint8_t l1pos[FPC_MAX_PL];           // own list: position after the GetGameResult reordering
   uint8_t newlist[3][FPC_MAX_PL];      // reordered lists (own, enemy a, enemy b) before they are copied back
-  uint8_t ent[200];                    // square -> 16*list + entry for the three lists a move can touch, else 0xFF
+  alignas(4) uint8_t ent[200];         // square -> 16*list + entry for the three lists a move can touch, else 0xFF (cleared 4 bytes per lane)
   int lk[2][48];                       // last move touching each list entry (GetGameResult's loop, GetLegalMoves' loop)
   int M, nlegal, first_legal, result, errbits;
   float scal_f;                        // wave-uniform scalar broadcast slot

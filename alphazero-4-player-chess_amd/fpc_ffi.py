@@ -117,6 +117,28 @@ def bind(cdll):
 _lib = None
 
 
+def _check_fresh():
+    """The in-tree library must have been built from the sources that lie beside it (__graft_entry__.build() stores
+    their content hash): a stale engine must not be tested or measured.  Variant libraries named by FPC_ENGINE_LIB
+    (A/B timing) are exempt."""
+    if os.environ.get("FPC_ENGINE_LIB"):
+        return
+    try:
+        want = open(LIB_PATH + ".srchash").read().strip()
+    except OSError:
+        return                                  # built by hand (hipcc ... -o libfpc_engine.so): nothing recorded
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_fpc_graft_entry", os.path.join(os.path.dirname(HERE), "__graft_entry__.py"))
+    ge = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ge)
+    csrc = os.path.join(HERE, "csrc")
+    srcs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".cpp", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(HERE), "include", "fpc_engine.h"))
+    if ge._src_hash(srcs, ge.HIPCC_FLAGS) != want:
+        raise RuntimeError("stale HIP engine library: %s was built from other sources than the ones beside it; "
+                           "rebuild with `python __graft_entry__.py`" % LIB_PATH)
+
+
 def lib():
     """The product library.  Raises if it has not been built (python __graft_entry__.py)."""
     global _lib
@@ -124,6 +146,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("HIP engine library missing: %s (build it with `python __graft_entry__.py`); "
                                "there is no CPU fallback" % LIB_PATH)
+        _check_fresh()
         # PyTorch-ROCm ships its own libamdhip64.so.7; it must be the copy already mapped when the
         # engine library is loaded, otherwise two HIP runtimes end up in one process and the second
         # one to initialise sees no GPU.  torch is plumbing here (device tensors for the evaluator

@@ -34,14 +34,17 @@ EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER
 _lib = None
 
 
+SAN = os.environ.get("FPC_SAN") == "1"      # tools/run_sanitized.sh: the ASan + UBSan build of the restatement
+
+
 def build():
-    subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+    subprocess.check_call(["make", "-s", "-C", HERE, "oracle"] + (["SAN=1"] if SAN else []))
 
 
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(HERE, "liboracle.so")
+        path = os.path.join(HERE, "liboracle_san.so" if SAN else "liboracle.so")
         src = os.path.join(HERE, "fpc_oracle.cpp")
         if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             build()

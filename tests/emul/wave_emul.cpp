@@ -1,7 +1,34 @@
 // tests/emul/wave_emul.cpp -- TEST INFRASTRUCTURE ONLY: fibre scheduler of the wavefront emulator.
 #include "wave_emul.h"
 
+// AddressSanitizer build (make SAN=1): every stack switch is announced, otherwise ASan takes the fibres' frames
+// for stack-buffer overflows of the main stack.
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/common_interface_defs.h>
+#define WEMU_ASAN 1
+#else
+#define WEMU_ASAN 0
+#endif
+
 namespace wemu {
+
+#if WEMU_ASAN
+static void *g_main_fake = nullptr, *g_lane_fake[MAX_THREADS];
+static const void *g_main_bottom = nullptr;
+static size_t g_main_size = 0;
+#endif
+// lane -> scheduler
+static void to_main(State &s, bool last) {
+#if WEMU_ASAN
+  __sanitizer_start_switch_fiber(last ? nullptr : &g_lane_fake[s.cur], g_main_bottom, g_main_size);
+#endif
+  const int me = s.cur;
+  swapcontext(&s.lane_ctx[me], &s.main_ctx);
+#if WEMU_ASAN
+  __sanitizer_finish_switch_fiber(g_lane_fake[me], &g_main_bottom, &g_main_size);
+#endif
+  (void)last;
+}
 
 State &st() {
   static State s;
@@ -10,16 +37,18 @@ State &st() {
 
 static void trampoline() {
   State &s = st();
+#if WEMU_ASAN
+  __sanitizer_finish_switch_fiber(nullptr, &g_main_bottom, &g_main_size);
+#endif
   s.body();
   s.done[s.cur] = true;
   s.block_live--;
   s.wave_live[s.cur / WAVE]--;
-  swapcontext(&s.lane_ctx[s.cur], &s.main_ctx);
+  to_main(s, true);
 }
 
 void yield() {
-  State &s = st();
-  swapcontext(&s.lane_ctx[s.cur], &s.main_ctx);
+  to_main(st(), false);
 }
 
 void run_grid(int grid, int block, const std::function<void()> &body) {
@@ -54,7 +83,13 @@ void run_grid(int grid, int block, const std::function<void()> &body) {
         if (s.done[l]) continue;
         any = true;
         s.cur = l;
+#if WEMU_ASAN
+        __sanitizer_start_switch_fiber(&g_main_fake, s.stacks[l], STK);
+#endif
         swapcontext(&s.main_ctx, &s.lane_ctx[l]);
+#if WEMU_ASAN
+        __sanitizer_finish_switch_fiber(g_main_fake, nullptr, nullptr);
+#endif
       }
       if (!any) break;
     }

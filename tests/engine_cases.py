@@ -225,12 +225,34 @@ def case_selfplay_trace(backend, R, max_traces=None):
     return n_checked
 
 
+def synthetic_entries(R, INV):
+    """A start layout for the board sizes the reference has no FEN for (9, 11, 12 a side; fpc_create accepts
+    8..14): each colour gets king, queen, two rooks, two knights, a bishop on its back rank inside the cross arm
+    and pawns on its second rank (the double-step line), Red bottom / Blue left / Yellow top / Green right as in
+    start_fens.py.  -> (turn, [(sq, colour, type), ...]) in row-major order."""
+    PAWN, KNIGHT, BISHOP, ROOK, QUEEN, KING = 0, 1, 2, 3, 4, 5
+    w = R - 2 * INV                                   # files of an arm
+    back = [ROOK, KNIGHT, BISHOP, QUEEN, KING, BISHOP, KNIGHT, ROOK]
+    back = (back[:w // 2] + back[len(back) - (w - w // 2):]) if w < 8 else back + [KNIGHT] * (w - 8)
+    if KING not in back:
+        back[len(back) // 2] = KING
+    cells = {}
+    for i in range(w):
+        f = INV + i
+        cells[(R - 1, f)] = (0, back[i]); cells[(R - 2, f)] = (0, PAWN)        # Red: bottom, moves up
+        cells[(f, 0)] = (1, back[i]); cells[(f, 1)] = (1, PAWN)                # Blue: left, moves right
+        cells[(0, f)] = (2, back[w - 1 - i]); cells[(1, f)] = (2, PAWN)        # Yellow: top, moves down
+        cells[(f, R - 1)] = (3, back[w - 1 - i]); cells[(f, R - 2)] = (3, PAWN)  # Green: right, moves left
+    return 0, [(r * R + c, col, typ) for (r, c), (col, typ) in sorted(cells.items())]
+
+
 def case_other_sizes_vs_oracle(backend, R, INV, n_games=6, sims=40, seed=5):
-    """10x10/2 and 13x13/3 (the reference's other start layouts, start_fens.py:18-56): no compiled
-    reference exists for them, so the engine is compared with the oracle (pinned at 8 and 14)."""
+    """10x10/2 and 13x13/3 (the reference's other start layouts, start_fens.py:18-56) and 9x9/2, 11x11/3,
+    12x12/3 (sizes fpc_create accepts without a reference layout: synthetic_entries): no compiled reference
+    exists for them, so the engine is compared with the oracle (pinned at 8 and 14)."""
     import random
     import positions
-    turn, entries = positions.start_entries(R)
+    turn, entries = positions.start_entries(R) if R in (8, 10, 13, 14) else synthetic_entries(R, INV)
     rng = random.Random(seed)
     eng = make_engine(backend, R, INV, max_games=n_games, max_sims=sims)
     roots_o = []

@@ -34,8 +34,9 @@ def emul_lib():
     """tests/emul/libfpc_emul.so: the product's tree-kernel source on the wavefront emulator."""
     global _emul
     if _emul is None:
-        subprocess.check_call(["make", "-s", "-C", os.path.join(TESTS, "emul")])
-        _emul = fpc_ffi.bind(C.CDLL(os.path.join(TESTS, "emul", "libfpc_emul.so")))
+        san = os.environ.get("FPC_SAN") == "1"       # tools/run_sanitized.sh: the ASan + UBSan build of the same sources
+        subprocess.check_call(["make", "-s", "-C", os.path.join(TESTS, "emul")] + (["SAN=1"] if san else []))
+        _emul = fpc_ffi.bind(C.CDLL(os.path.join(TESTS, "emul", "libfpc_emul_san.so" if san else "libfpc_emul.so")))
     return _emul
 
 

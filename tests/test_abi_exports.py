@@ -46,3 +46,18 @@ def test_engine_creation_fails_loudly_without_a_gpu():
     import pytest
     with pytest.raises(RuntimeError, match="no HIP device|fpc_create failed"):
         fpc_ffi.Engine(8, 2, max_games=1, max_sims=1)
+
+
+def test_a_library_built_from_other_sources_is_refused(tmp_path, monkeypatch):
+    """__graft_entry__.build() stores the content hash of the sources beside the .so; fpc_ffi refuses to load a
+    library whose recorded hash is not the hash of the sources in the tree (mtimes say nothing after a checkout)."""
+    import shutil
+    import pytest
+    monkeypatch.delenv("FPC_ENGINE_LIB", raising=False)
+    fpc_ffi._check_fresh()                                   # the in-tree library is fresh
+    fake = tmp_path / "libfpc_engine.so"
+    shutil.copy(fpc_ffi.LIB_PATH, fake)
+    (tmp_path / "libfpc_engine.so.srchash").write_text("0" * 64 + "\n")
+    monkeypatch.setattr(fpc_ffi, "LIB_PATH", str(fake))
+    with pytest.raises(RuntimeError, match="stale HIP engine library"):
+        fpc_ffi._check_fresh()

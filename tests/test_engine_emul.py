@@ -37,7 +37,7 @@ def test_selfplay_trace_r8():
     assert ec.case_selfplay_trace("emul", 8, max_traces=1) > 100     # the GPU suite replays every trace at both sizes
 
 
-@pytest.mark.parametrize("R,INV", [(10, 2), (13, 3)])
+@pytest.mark.parametrize("R,INV", [(10, 2), (13, 3), (9, 2), (11, 3), (12, 3)])
 def test_other_board_sizes_vs_oracle(R, INV):
     assert ec.case_other_sizes_vs_oracle("emul", R, INV, n_games=3, sims=20)
 

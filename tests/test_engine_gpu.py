@@ -45,7 +45,7 @@ def test_selfplay_trace(R):
     assert ec.case_selfplay_trace("gpu", R) >= 94
 
 
-@pytest.mark.parametrize("R,INV", [(10, 2), (13, 3)])
+@pytest.mark.parametrize("R,INV", [(10, 2), (13, 3), (9, 2), (11, 3), (12, 3)])
 def test_other_board_sizes_vs_oracle(R, INV):
     assert ec.case_other_sizes_vs_oracle("gpu", R, INV, n_games=24, sims=80)
 

@@ -44,14 +44,15 @@ def _model(R, blocks, hidden, seed=0):
     return m.eval()
 
 
-INV_OF = {8: 2, 10: 2, 13: 3, 14: 3}
+INV_OF = {8: 2, 9: 2, 10: 2, 11: 3, 12: 3, 13: 3, 14: 3}
 
 
 def _positions(R, n):
     if R not in (8, 14):          # no reference build at this size: random legal playouts on the engine itself
         import random
         import positions
-        turn, entries = positions.start_entries(R)
+        from engine_cases import synthetic_entries
+        turn, entries = positions.start_entries(R) if R in (10, 13) else synthetic_entries(R, INV_OF[R])
         eng = make_engine("gpu", R, INV_OF[R], max_games=4, max_sims=4)
         rng = random.Random(R)
         b = fpc_ffi.board_from_dict(R, turn, entries)
@@ -78,7 +79,9 @@ def _positions(R, n):
 @pytest.mark.parametrize("R,blocks,hidden,dtype,tol", [(8, 4, 64, 1, 1e-3), (8, 4, 64, 0, 8e-3), (8, 2, 128, 1, 1e-3),
                                                        (14, 2, 64, 1, 1e-3), (14, 2, 64, 0, 8e-3),
                                                        (14, 3, 128, 1, 1e-3), (14, 3, 128, 0, 8e-3), (8, 3, 128, 0, 8e-3),
-                                                       (8, 2, 256, 1, 1e-3), (10, 2, 128, 1, 1e-3)])
+                                                       (8, 2, 256, 1, 1e-3), (10, 2, 128, 1, 1e-3),
+                                                       # sizes without a reference layout: every k_tower row-tile variant
+                                                       (9, 2, 128, 1, 1e-3), (11, 2, 128, 1, 1e-3), (12, 2, 128, 1, 1e-3), (13, 2, 128, 1, 1e-3)])
 def test_resnet_forward_vs_torch_fp32(R, blocks, hidden, dtype, tol):
     """north_star tolerance: policy/value logits within 1e-3 of the fp32 reference.  Met with fp16
     MFMA operands; bf16 (8 mantissa bits) is reported with its own, looser, bound."""

@@ -10,7 +10,8 @@ if os.environ.get('FPC_UNUSED_VARIANT_LIB'):
 from bench import Spec
 R, G, iters = 14, 256, int(sys.argv[1]) if len(sys.argv) > 1 else 5
 torch.manual_seed(0)
-m = net.ResNet(Spec(R), 10, 128, "cpu").eval()
+NB, NH = int(os.environ.get("FPC_NN_BLOCKS", "10")), int(os.environ.get("FPC_NN_HIDDEN", "128"))   # configs[3]: 20 / 256
+m = net.ResNet(Spec(R), NB, NH, "cpu").eval()
 DT = int(os.environ.get("FPC_NN_DTYPE", "1"))   # 1 = fp16 (the headline operand type), 0 = bf16
 eng = fpc_ffi.Engine(R, 3, max_games=G, max_sims=8, nn_dtype=DT)
 eng.load_weights(weights.export_weights(m, DT))

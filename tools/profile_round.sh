@@ -1,10 +1,11 @@
 # One GPU call that produces everything profiles/ holds for a round (run from the repo root on the GPU box):
-#   bash tools/profile_round.sh r02
+#   bash tools/profile_round.sh r03 A     and     bash tools/profile_round.sh r03 B     (two GPU calls of <= 20 min)
 # 1. rocprofv3 --kernel-trace --stats of the DEFAULT bench command (the summary the roofline numbers must agree with)
 # 2. PMC passes over the network forward (tools/pmc_nn.sh; separate --pmc passes, no trace domains mixed in)
 # 3. configs[3] (ResNet(20,256), 800 sims, fp16) and the 8x8 literal-snapshot size: bench lines + kernel stats
 # 4. power / clock samples during a bench run
 TAG=${1:-rXX}
+PART=${2:-AB}      # A: default stats + PMC passes (both networks); B: configs[3] / 8x8 / arena / memory-side PMC / power / default run
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
 stats() {   # stats <name> <bench flags...>
@@ -14,10 +15,25 @@ stats() {   # stats <name> <bench flags...>
   cp gpurun_out/prof_$name/*/*kernel_stats.csv gpurun_out/$TAG/${name}_kernel_stats.csv 2>/dev/null || echo "no stats for $name"
   echo "== $name"; head -8 gpurun_out/$TAG/${name}_kernel_stats.csv | cut -d, -f1-5; cut -c1-300 gpurun_out/$TAG/${name}_bench.json
 }
+if [[ $PART == *A* ]]; then
 stats default --no-cpu-baseline --no-alt-policy-head --no-alt-dtype
 bash tools/pmc_nn.sh > gpurun_out/$TAG/pmc_nn.log 2>&1; tail -20 gpurun_out/$TAG/pmc_nn.log | cut -c1-400
 for p in a b c d e f; do cp gpurun_out/pmc_$p/*/*counter_collection.csv gpurun_out/$TAG/pmc_$p.csv 2>/dev/null; done
-stats config3 --blocks 20 --hidden 256 --sims 800 --dtype fp16 --steps 3 --warmup 1 --no-cpu-baseline --no-alt-policy-head --no-alt-dtype
+python3 tools/pmc_summary.py gpurun_out/$TAG r14_b10_h128_g256 > gpurun_out/$TAG/pmc_summary_c1.txt 2>&1
+# the same passes over configs[3]'s network (k_tower256): bench.py prices a kernel only with its own counters
+mkdir -p gpurun_out/$TAG/c3
+PMC_TAG=c3_ FPC_NN_BLOCKS=20 FPC_NN_HIDDEN=256 bash tools/pmc_nn.sh > gpurun_out/$TAG/pmc_nn_c3.log 2>&1; tail -8 gpurun_out/$TAG/pmc_nn_c3.log | cut -c1-300
+for p in a b c d e f; do cp gpurun_out/pmc_c3_$p/*/*counter_collection.csv gpurun_out/$TAG/c3/pmc_$p.csv 2>/dev/null; done
+python3 tools/pmc_summary.py gpurun_out/$TAG/c3 r14_b20_h256_g256 > gpurun_out/$TAG/pmc_summary_c3.txt 2>&1
+cp profiles/pmc_summary.json gpurun_out/$TAG/pmc_summary.json
+fi
+if [[ $PART == *B* ]]; then
+stats config3 --config 3 --steps 3 --warmup 1 --no-cpu-baseline --no-alt-policy-head --no-alt-dtype
 stats board8 --board 8 --steps 6 --no-cpu-baseline --no-alt-policy-head --no-alt-dtype
+python3 tools/arena_bench.py > gpurun_out/$TAG/arena_1024.json 2> gpurun_out/$TAG/arena_1024.err; cut -c1-400 gpurun_out/$TAG/arena_1024.json
+bash tools/pmc_fc_mem.sh > gpurun_out/$TAG/pmc_fc_mem.log 2>&1; tail -12 gpurun_out/$TAG/pmc_fc_mem.log | cut -c1-400
+for p in a b c d e f; do cp gpurun_out/pmcm_$p/*/*counter_collection.csv gpurun_out/$TAG/pmcm_$p.csv 2>/dev/null; done
 bash tools/power_probe.sh --no-alt-dtype > gpurun_out/$TAG/power_probe.log 2>&1; cp gpurun_out/power_samples.txt gpurun_out/$TAG/power_samples.txt; tail -3 gpurun_out/$TAG/power_probe.log | cut -c1-300
 python3 bench.py > gpurun_out/$TAG/default_run.json 2> gpurun_out/$TAG/default_run.err; cut -c1-200 gpurun_out/$TAG/default_run.json
+
+fi

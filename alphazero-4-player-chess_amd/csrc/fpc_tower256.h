@@ -30,6 +30,12 @@ constexpr int T2_KS = 8;                         // k-steps per tap (256 / 32)
 
 // tw_dma_4k (4 consecutive 1-KiB LDS-DMA pieces): fpc_tower.h
 
+#ifndef T2_STREAM
+#define T2_STREAM 0              // 0: a slab's four DMA pieces per wave go out as a burst behind the k-step barrier.  1 (k_tower's
+                                 // scheme: one M0 write, pieces between the first MFMA groups): measured 4.5 % SLOWER on the same box
+                                 // (2.78 -> 2.91 ms): with only two slab buffers a slab has ONE k-step to land, and every cycle a
+                                 // piece is issued later is a cycle the next barrier waits longer
+#endif
 // TowerArgs as for k_tower, with: Wstem = 9 slabs, Wt = (L + 2) * 72 slabs, bt = [L + 2][256].  14x14 only.
 template <int DT>
 __global__ void __launch_bounds__(TW_THREADS, 1) k_tower256(TowerArgs g) {
@@ -214,7 +220,24 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower256(TowerArgs g) {
     constexpr int N = B ^ 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#if T2_STREAM
+    // slab gk + 2: M0 and the source base once, right behind the barrier (no LDS read in flight: an s_mov to M0
+    // waits for those); its four pieces then go out between the first MFMA groups through the instruction's
+    // immediate (fpc_tower.h: tw_dma_piece), where they cost ~6 cycles each instead of ~64 as a burst
+    const unsigned char *dsrc;
+    {
+      const int gn = gk + 2, gc = gn < total ? gn : total - 1;
+      if (gn % (9 * T2_KS) == 0 && gn < total) {
+        const int l = gn / (9 * T2_KS);
+        tw_dma_256(reinterpret_cast<const unsigned char *>(g.bt + (size_t)l * 256 + wave * 64), (uint32_t)lane * 4u,
+                   (uint32_t)__builtin_amdgcn_readfirstlane(TW_BIAS + ((l & 1) * 256 + wave * 64) * 4));
+      }
+      dsrc = g.Wt + (size_t)gc * T2_SLAB + wave * 4096;
+      tw_set_m0((uint32_t)__builtin_amdgcn_readfirstlane(T2_RING + (gn & 1) * T2_SLAB + wave * 4096));
+    }
+#else
     issue_slab(gk + 2);
+#endif
     const unsigned char *sl = ring + ((gk + 1) & 1) * T2_SLAB + cb_next * 64 + apart_s;
     ++gk;
     __builtin_amdgcn_sched_barrier(0);
@@ -232,6 +255,13 @@ __global__ void __launch_bounds__(TW_THREADS, 1) k_tower256(TowerArgs g) {
       fa[N][mt] = *reinterpret_cast<const t_u32x4 *>(sl + mt * 1024);
       if (mt == MT - 1) fa[N][7] = *reinterpret_cast<const t_u32x4 *>(sl + 7 * 1024);
       __builtin_amdgcn_sched_barrier(0);
+#if T2_STREAM
+      if (mt == 0) tw_dma_piece<0>(dsrc, dma_lane);
+      if (mt == 1) tw_dma_piece<1024>(dsrc, dma_lane);
+      if (mt == 2) tw_dma_piece<2048>(dsrc, dma_lane);
+      if (mt == 3) tw_dma_piece<3072>(dsrc, dma_lane);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
   };
   const std::integral_constant<int, 3> c3{};

@@ -325,9 +325,18 @@ class MemoryEntry:                      # board.h:133-140: Board held BY VALUE +
 
 
 class Node:
-    """Read-only view of a search-tree node kept on the device (node.h:17-79).  Only what the
-    training loop reads is provided (alphazero.py:104-110): GetChildren / GetMoveMade /
-    GetVisitCount / GetState / IsExpanded."""
+    """A search-tree node (node.h:17-79, wrapper.cpp:233-253).
+
+    Two kinds of object share this class.  `MCTS.search` (mcts.py here) keeps the whole tree on the GPU
+    and hands back READ-ONLY views of the roots: GetChildren / GetMoveMade / GetVisitCount / GetState /
+    IsExpanded, which is all the training loop reads (alphazero.py:104-110).  A `Node(C, state, ...)`
+    built by the caller is a HOST tree node with the reference's full method set -- ChooseLeaf,
+    SelectChild, Backpropagate, BackpropagateNodes, ExpandNodes (node.cpp:19-154), so that code written
+    against the reference's per-simulation loop (its own mcts.py:17-89) runs unchanged: the tree
+    bookkeeping is restated here in Python (f64 PUCT with IEEE sqrt / libm log, strict `>`: the lowest
+    index wins ties), every board operation underneath (GetGameResult, the child boards of an expansion,
+    encode, legal moves) still goes through the engine's C-ABI.  It is the compatibility path, orders of
+    magnitude slower than MCTS.search, and never used by it."""
 
     def __init__(self, C=0.0, state=None, parent=None, action_taken=None, prior=0.0, visit_count=0):
         self._C, self._state, self._parent, self._move = C, state, parent, action_taken
@@ -357,12 +366,75 @@ class Node:
     def IsExpanded(self):
         return len(self.GetChildren()) > 0
 
-    def _device_only(self, *a, **k):
-        raise RuntimeError("the search tree lives on the GPU: drive it through MCTS.search (mcts.py); "
-                           "per-node SelectChild/Backpropagate/ExpandNodes/ChooseLeaf have no host form")
+    # ---- host forms (node.cpp) ----------------------------------------------------------------------------
+    def _host_only(self):
+        if self._state is None:
+            raise RuntimeError("this node is a read-only view of a tree that lives on the GPU (MCTS.search): it has no "
+                               "state to descend into; build host nodes with Node(C, state, ...)")
 
-    SelectChild = Backpropagate = ChooseLeaf = _device_only
-    BackpropagateNodes = ExpandNodes = staticmethod(_device_only)
+    def SelectChild(self):              # node.cpp:49-78
+        import numpy as np
+        kids = self._children
+        with np.errstate(all="ignore"):
+            log_parent = np.log(np.sqrt(np.float64(self._n)))
+            best, best_ucb = -1, -np.inf
+            for i, ch in enumerate(kids):
+                n = ch._n
+                q = np.float64(ch._value_sum) / n if n > 0 else np.float64(0.0)
+                ucb = q + np.float64(self._C) * np.sqrt(log_parent / np.float64(1 + n)) * np.float64(ch._prior)
+                if ucb > best_ucb:
+                    best, best_ucb = i, ucb
+        if best < 0:
+            raise RuntimeError("Failed to select a child.")
+        return kids[best]
+
+    def ChooseLeaf(self):               # node.cpp:19-47
+        self._host_only()
+        node = self
+        while node._children:
+            node = node.SelectChild()
+        result = node._state.GetGameResult()
+        if result != GameResult.IN_PROGRESS:
+            node.Backpropagate(0.0 if result == GameResult.STALEMATE else -1.0)
+            return None
+        return node
+
+    def Backpropagate(self, value):     # node.cpp:133-142: value_sum (double) += value (float); the sign flips per ply
+        import numpy as np
+        v = float(np.float32(value))
+        node = self
+        while node is not None:
+            node._value_sum += v
+            node._n += 1
+            v = -v
+            node = node._parent
+
+    @staticmethod
+    def BackpropagateNodes(nodes, values):          # node.cpp:144-154
+        vals = values.detach().to("cpu").reshape(-1).tolist() if hasattr(values, "detach") else list(values)
+        for node, v in zip(nodes, vals):
+            node.Backpropagate(v)
+
+    @staticmethod
+    def ExpandNodes(nodes, policy_batch, non_zero_indices_batch, non_zero_values, pool):      # node.cpp:79-131
+        """children in the order of the non-zero (plane, row, col) entries; each child's board is the parent's
+        board after Move(plane, from) -- from / to only (Q9) -- and starts with visit_count 1 (node.h:28, Q1)"""
+        per = [[] for _ in nodes]
+        for (b, plane, row, col), prob in zip(non_zero_indices_batch, non_zero_values):
+            per[int(b)].append((Move(int(plane), BoardLocation(int(row), int(col))), float(prob)))
+        pods, flats = [], []
+        for node, entries in zip(nodes, per):
+            node._host_only()
+            for mv, _p in entries:
+                pods.append(node._state._b)
+                flats.append(mv.GetFlatIndex())
+        made = engine(min_games=1).take_action(pods, flats) if pods else []
+        k = 0
+        for node, entries in zip(nodes, per):
+            for mv, prob in entries:
+                child_state = Board._wrap(made[k], like=node._state)
+                k += 1
+                node._children.append(Node(node._C, child_state, node, mv, prob, 1))
 
 
 class Board:                            # board.h:18-131, wrapper.cpp:165-226

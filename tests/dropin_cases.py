@@ -127,3 +127,93 @@ def case_training_loop(backend, R=8):
     assert a.history and all(np.isfinite(h["loss"]) for h in a.history)
     assert any(not torch.equal(b, p.detach()) for b, p in zip(before, model.parameters()))
     return len(a.history)
+
+
+# ---- host forms of the Node API (wrapper.cpp:233-253): the reference's per-simulation loop runs on the shim ----
+def _host_tree_search(az, game_type, games, evaluator, C, sims):
+    """A per-simulation search written against nothing but the bound API of the reference (Node.ChooseLeaf,
+    Board.GetEncodedStates / ParseActionspace, get_legal_moves_mask, Node.BackpropagateNodes / ExpandNodes) --
+    the contract its own mcts.py:17-89 programs against, in our own words."""
+    roots = []
+    for g in games:
+        roots.append(az.Node(C, g, visit_count=1))
+        g.SetRootNode(roots[-1])
+    live = list(roots)
+    pool = az.BoardPool(10)
+    for _sim in range(sims):
+        leaves, still = [], []
+        for r in live:                      # a root whose descent ended in a terminal leaf leaves the search (Q5)
+            leaf = r.ChooseLeaf()
+            if leaf is not None:
+                leaves.append(leaf)
+                still.append(r)
+        live = still
+        if not leaves:
+            continue
+        states = [l.GetState() for l in leaves]
+        logits, value = evaluator(game_type.GetEncodedStates(states, "cpu"))
+        p = game_type.ParseActionspace(torch.softmax(logits, dim=1), states[0].GetTurn())
+        p = p * game_type.get_legal_moves_mask(states, "cpu")
+        p = p / p.sum(dim=(1, 2, 3), keepdim=True)
+        az.Node.BackpropagateNodes(leaves, value.squeeze(1))
+        nz = torch.nonzero(p)
+        az.Node.ExpandNodes(leaves, p, nz.tolist(), p[tuple(nz.t())].tolist(), pool)
+    return roots
+
+
+def _load_reference_mcts():
+    """the reference's OWN src/py/mcts.py (only where /root/reference exists: the build container), bound to our
+    shim: `alphazero_cpp` resolves to alphazero-4-player-chess_amd/alphazero_cpp.py; its one foreign import
+    (line_profiler_pycharm.profile, a PyCharm plugin) gets an identity decorator"""
+    import importlib.util
+    import os
+    import sys
+    import types
+    path = "/root/reference/src/py/mcts.py"
+    if not os.path.exists(path):
+        return None
+    if "line_profiler_pycharm" not in sys.modules:
+        stub = types.ModuleType("line_profiler_pycharm")
+        stub.profile = lambda f: f
+        sys.modules["line_profiler_pycharm"] = stub
+    spec = importlib.util.spec_from_file_location("reference_mcts_py", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def case_host_tree(backend, R, max_cases=3, max_sims=100, use_reference_mcts=False):
+    """Golden MCTS.search cases of the real reference, re-run through the HOST forms of Node (tree bookkeeping
+    in the shim, board operations through the engine's C-ABI): root and second-level visit counts must match
+    the reference bit for bit; with use_reference_mcts the loop that runs IS the reference's own mcts.py."""
+    az = setup(backend, R)
+    from fen_parser import parse_board_args_from_fen
+    from four_player_chess_board import FourPlayerChess
+    ref_mod = _load_reference_mcts() if use_reference_mcts else None
+    if use_reference_mcts and ref_mod is None:
+        return -1
+    g = gold(R)
+    done = 0
+    for rec in g["searches"]:
+        if rec["kind"] not in ("zero", "hash") or rec["sims"] > max_sims or len(rec["before"]) != 1 or done >= max_cases:
+            continue
+        game = FourPlayerChess(*parse_board_args_from_fen(FourPlayerChess.start_fen, R))
+        start_pl = [[[pp.GetLocation().GetRow() * R + pp.GetLocation().GetCol(), int(pp.GetPiece().GetPieceType())]
+                     for pp in col] for col in game.GetPieces()]
+        if start_pl != rec["before"][0]["pl"] or int(game.GetTurn().GetColor()) != rec["before"][0]["turn"]:
+            continue                        # a case that does not start from the start position
+        ev = Eval(rec["kind"], R)
+        if ref_mod is not None:
+            m = ref_mod.MCTS(FourPlayerChess, ev, {"C": rec["C"], "num_searches": rec["sims"], "pool_size": 10})
+            roots = m.search([game])
+        else:
+            roots = _host_tree_search(az, FourPlayerChess, [game], ev, rec["C"], rec["sims"])
+        ref = rec["roots"][0]
+        assert roots[0].GetVisitCount() == ref["root_n"]
+        assert [[c.GetMoveMade().GetFlatIndex(), c.GetVisitCount()] for c in roots[0].GetChildren()] == [[c[0], c[1]] for c in ref["children"]]
+        assert [[c.GetMoveMade().GetFlatIndex(), c.GetVisitCount()] for c in roots[0].GetChildren()[0].GetChildren()] == ref["children"][0][2]
+        state_pl = [[[pp.GetLocation().GetRow() * R + pp.GetLocation().GetCol(), int(pp.GetPiece().GetPieceType())]
+                     for pp in col] for col in game.GetPieces()]
+        assert state_pl == ref["after"]
+        done += 1
+    return done

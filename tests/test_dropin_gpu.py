@@ -99,3 +99,10 @@ def test_native_tuples_and_rccl_single_rank():
     for ply, (res, roots) in enumerate(results):
         assert np.array_equal(enc[ply * G].numpy(), eng.encode([roots[0]])[0])
     eng.close()
+
+
+@pytest.mark.parametrize("R", [8, 14])
+def test_host_node_forms_reproduce_reference_searches(R):
+    """Node.ChooseLeaf / SelectChild / Backpropagate(Nodes) / ExpandNodes as host methods (wrapper.cpp:233-253);
+    board operations on the GPU through the C-ABI; golden visit counts of the real reference."""
+    assert dc.case_host_tree("gpu", R, max_cases=3, max_sims=100) >= 1

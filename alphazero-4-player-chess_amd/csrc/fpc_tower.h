@@ -196,6 +196,13 @@ __device__ __forceinline__ void tw_dma_256(const unsigned char *gsrc_uniform, ui
 #ifndef TW_LOADERS
 #define TW_LOADERS 1
 #endif
+// TW_STAGGER (8-wave form with TW_LOADERS 1): the waves that carry no DMA (4-7) pass the tap barrier half a tap
+// EARLIER in their k-step sequence (in front of k-steps 1, 2 instead of behind them), so that the two waves of a
+// SIMD are never in their tap transition together.  Needs the burst form of the stream (TW_AHEAD 1 semantics):
+// behind barrier t the staggered waves still read slot t.
+#ifndef TW_STAGGER
+#define TW_STAGGER 0
+#endif
 
 // NW: waves per workgroup.  4 = one wave per SIMD, wave (wm, wn) owns MT row tiles x 4 column tiles (64 output
 // channels).  8 = two waves per SIMD, each with half the register file: wave (wm, wn) owns MT row tiles x 2 column
@@ -213,6 +220,8 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
   constexpr int PIECES = 4 * LOAD;                 // 1-KiB pieces of a tap this wave brings in
   constexpr int DMA_PER_WAVE = PIECES * 1024;
   constexpr int MID = PIECES == 8 ? 4096 : 0;      // the stream base sits in the middle of an 8-KiB share (immediates reach -4096 .. 4095)
+  constexpr bool STREAM = TW_AHEAD == 2 && !(TW_STAGGER && NW == 8 && TW_LOADERS == 1);   // pieces between the MFMAs, two taps ahead
+  constexpr bool STAG = TW_STAGGER && NW == 8 && TW_LOADERS == 1 && LOAD == 0;            // this wave passes the tap barrier half a tap early
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *const img = smem + TW_IMG0;
   unsigned char *const ring = smem + TW_RING;
@@ -356,7 +365,7 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
   };
   issue_tap(0);
   issue_tap(1);
-  if (TW_AHEAD == 2) {                             // first quarter of tap 2; the k-steps carry on from there
+  if (STREAM) {                                    // first quarter of tap 2; the k-steps carry on from there
     open_tap(2);
     piece(std::integral_constant<int, 0>{});
     if (LOAD == 2) piece(std::integral_constant<int, 1>{});
@@ -391,7 +400,7 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
   const std::integral_constant<int, 2> c2{};
   const std::integral_constant<int, 3> c3{};
   epilogue(c1);                  // stem: x_0 = relu(conv + b)
-  if (TW_AHEAD == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES + LOAD) : "memory");   // tap 1 and the first quarter of tap 2 stay in flight
+  if (STREAM) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES + LOAD) : "memory");   // tap 1 and the first quarter of tap 2 stay in flight
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();               // x_0 complete, tap 0 and layer 0's biases landed
 
@@ -455,7 +464,7 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
         fb[N][mt + 1] = *reinterpret_cast<const t_u32x4 *>(bptr(mt + 1) + KSN * 512);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (TW_AHEAD == 2 && LOAD != 0) {
+      if (STREAM && LOAD != 0) {
         if (mt == (LOAD == 2 ? MT / 3 : MT / 2)) piece(std::integral_constant<int, LOAD * Q>{});
         if (LOAD == 2 && mt == (2 * MT) / 3) piece(std::integral_constant<int, LOAD * Q + 1>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -481,23 +490,31 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
     kstep(mode_c, c0, c1, c1, b4, c1);             // (tap 0, k-step 0), C = bias
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
+      if (STAG) {                                  // (this wave issued no DMA: nothing to wait for)
+        TW_STAMP(gt, 3);
+        __syncthreads();
+        TW_STAMP(gt, 4);
+      }
       TW_STAMP(gt, 0);
       kstep(mode_c, c1, c2, c0, b4, c2);           // k-step 1
       TW_STAMP(gt, 1);
       kstep(mode_c, c0, c3, c0, b4, c3);           // k-step 2
       TW_STAMP(gt, 2);
-      // tap gt + 1's weights: every wave's pieces of it have landed (TW_AHEAD 2: tap gt + 2's stay in flight),
-      // and nobody reads slot gt % 3 any more -- the fragments of this tap's last k-step are in registers -- so
-      // (TW_AHEAD 2) tap gt + 3 goes there.  Also: all fragment reads of this tap are complete, so after tap 8
-      // the epilogue may rewrite the image in place.
-      if (TW_AHEAD == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      TW_STAMP(gt, 3);
-      __syncthreads();
-      TW_STAMP(gt, 4);
-      if (TW_AHEAD == 2) open_tap(gt + 3);
-      else if (gt + 2 < total) issue_tap(gt + 2);
-      TW_STAMP(gt, 5);
+      // tap gt + 1's weights: every wave's pieces of it have landed (STREAM: tap gt + 2's stay in flight), and
+      // nobody reads slot gt % 3 any more -- the fragments of this tap's last k-step are in registers -- so
+      // (STREAM) tap gt + 3 goes there.  Also: all fragment reads of this tap are complete, so after tap 8 the
+      // epilogue may rewrite the image in place (the staggered waves read on behind barrier 8, but only image
+      // rows of their own half and below: tap 8 looks down-right).
+      if (!STAG) {
+        if (STREAM) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TW_STAMP(gt, 3);
+        __syncthreads();
+        TW_STAMP(gt, 4);
+        if (STREAM) open_tap(gt + 3);
+        else if (gt + 2 < total) issue_tap(gt + 2);
+        TW_STAMP(gt, 5);
+      }
       ++gt;
       set_tap(tap == 8 ? 0 : tap + 1, tap == 8 ? cb_next : cb);
       TW_STAMP(gt - 1, 6);

@@ -196,12 +196,17 @@ __device__ __forceinline__ void tw_dma_256(const unsigned char *gsrc_uniform, ui
 #ifndef TW_LOADERS
 #define TW_LOADERS 1
 #endif
-// TW_STAGGER (8-wave form with TW_LOADERS 1): the waves that carry no DMA (4-7) pass the tap barrier half a tap
-// EARLIER in their k-step sequence (in front of k-steps 1, 2 instead of behind them), so that the two waves of a
-// SIMD are never in their tap transition together.  Needs the burst form of the stream (TW_AHEAD 1 semantics):
-// behind barrier t the staggered waves still read slot t.
+// TW_STAGGER = S (8-wave form with TW_LOADERS 1): the waves that carry no DMA (4-7) pass every tap barrier S k-steps
+// EARLIER in their k-step sequence than the loader waves (S = 3: in front of a tap's k-step 0 instead of behind its
+// k-step 2).  A barrier releases all waves at the same instant; what the stagger changes is where in its program each
+// wave of a SIMD pair then stands: the loader goes into its DMA burst and address arithmetic while its partner runs
+// four k-steps of MFMAs, instead of both standing in the same transition.  At a layer's end the early half still has
+// S + 1 k-steps to go while the loader half converts its accumulators -- legal because the last tap looks down-right
+// and therefore reads only image rows of the late half's own tiles and below.  Needs the burst form of the stream
+// (behind barrier t the staggered waves still read slot t, so tap t + 3 cannot go there yet).
+// Same-box A/B, k_tower per launch, logits bit-identical: S = 0 / 1 / 2 / 3: 0.2874 / 0.2771 / 0.2757 / 0.2653 ms.
 #ifndef TW_STAGGER
-#define TW_STAGGER 0
+#define TW_STAGGER 3
 #endif
 
 // NW: waves per workgroup.  4 = one wave per SIMD, wave (wm, wn) owns MT row tiles x 4 column tiles (64 output
@@ -220,8 +225,8 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
   constexpr int PIECES = 4 * LOAD;                 // 1-KiB pieces of a tap this wave brings in
   constexpr int DMA_PER_WAVE = PIECES * 1024;
   constexpr int MID = PIECES == 8 ? 4096 : 0;      // the stream base sits in the middle of an 8-KiB share (immediates reach -4096 .. 4095)
-  constexpr bool STREAM = TW_AHEAD == 2 && !(TW_STAGGER && NW == 8 && TW_LOADERS == 1);   // pieces between the MFMAs, two taps ahead
-  constexpr bool STAG = TW_STAGGER && NW == 8 && TW_LOADERS == 1 && LOAD == 0;            // this wave passes the tap barrier half a tap early
+  constexpr bool STREAM = TW_AHEAD == 2 && !(TW_STAGGER != 0 && NW == 8 && TW_LOADERS == 1);   // pieces between the MFMAs, two taps ahead
+  constexpr int STAG = (NW == 8 && TW_LOADERS == 1 && LOAD == 0) ? TW_STAGGER : 0;        // k-steps this wave passes the tap barrier early (0..3)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *const img = smem + TW_IMG0;
   unsigned char *const ring = smem + TW_RING;
@@ -487,10 +492,11 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
 #pragma unroll
       for (int ct = 0; ct < (MODE == 0 ? CT : 1); ++ct) b4[ct] = *reinterpret_cast<const t_f32x4 *>(bl + ct * 16);
     }
+    if (STAG == 3) __syncthreads();                // (a staggered wave issued no DMA: nothing to wait for)
     kstep(mode_c, c0, c1, c1, b4, c1);             // (tap 0, k-step 0), C = bias
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
-      if (STAG) {                                  // (this wave issued no DMA: nothing to wait for)
+      if (STAG == 2) {
         TW_STAMP(gt, 3);
         __syncthreads();
         TW_STAMP(gt, 4);
@@ -498,6 +504,7 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
       TW_STAMP(gt, 0);
       kstep(mode_c, c1, c2, c0, b4, c2);           // k-step 1
       TW_STAMP(gt, 1);
+      if (STAG == 1) __syncthreads();
       kstep(mode_c, c0, c3, c0, b4, c3);           // k-step 2
       TW_STAMP(gt, 2);
       // tap gt + 1's weights: every wave's pieces of it have landed (STREAM: tap gt + 2's stay in flight), and
@@ -520,6 +527,7 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
       TW_STAMP(gt - 1, 6);
       kstep(mode_c, c1, c0, c0, b4, c0);           // k-step 3, reading (next tap, k-step 0)
       TW_STAMP(gt - 1, 7);
+      if (STAG == 3 && tap < 8) __syncthreads();
       if (tap < 8) kstep(mode_c, c0, c1, c0, b4, c1);  // (next tap, k-step 0)
       TW_STAMP(gt - 1, 8);
     }

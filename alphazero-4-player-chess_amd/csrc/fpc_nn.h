@@ -666,6 +666,8 @@ struct NN {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 7, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 7, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 3, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 5, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 7, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
         attr = true;
       }
       if (use_tower256) {
@@ -674,7 +676,9 @@ struct NN {
         hipLaunchKernelGGL((k_tower256<DT>), dim3(n), dim3(TW_THREADS), T2_LDS, stream, t);
       } else if (mt == 3 && tower_waves == 8) hipLaunchKernelGGL((k_tower<DT, 3, false, 8>), dim3(n), dim3(512), TW_LDS, stream, t);
       else if (mt == 3) hipLaunchKernelGGL((k_tower<DT, 3, false, 4>), dim3(n), dim3(256), TW_LDS, stream, t);
+      else if (mt == 5 && tower_waves == 8) hipLaunchKernelGGL((k_tower<DT, 5, false, 8>), dim3(n), dim3(512), TW_LDS, stream, t);
       else if (mt == 5) hipLaunchKernelGGL((k_tower<DT, 5, false, 4>), dim3(n), dim3(256), TW_LDS, stream, t);
+      else if (P != 16 && tower_waves == 8) hipLaunchKernelGGL((k_tower<DT, 7, false, 8>), dim3(n), dim3(512), TW_LDS, stream, t);
       else if (P != 16) hipLaunchKernelGGL((k_tower<DT, 7, false, 4>), dim3(n), dim3(256), TW_LDS, stream, t);
       // 14x14 (grid pitch == tile height): two waves per SIMD, 7 x 2 tiles each
       else if (tower_waves == 8) hipLaunchKernelGGL((k_tower<DT, 7, true, 8>), dim3(n), dim3(512), TW_LDS, stream, t);

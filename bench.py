@@ -13,10 +13,13 @@ MFMA operand type: fp16 by default -- it is the 16-bit type that meets north_sta
 within 1e-3 of the reference's fp32 net.py: 3.1e-4, tests/test_net_gpu.py) at the same MFMA rate;
 configs[1]'s bf16 does not (2.3e-3) and is measured right after the timed region and reported beside
 the headline as `alt_dtype_bf16` with both measured errors in `float_parity`.
-N > 1: one process per GPU (torchrun), games sharded 256/GPU (weak scaling), no data-path collective
-inside the search; training tuples are built on the device (fpc_collect_tuples) and the all-gather
-that ends an episode is one ncclAllGather issued by the engine's C++ host over RCCL/xGMI
-(fpc_allgather_tuples), executed once inside the timed region.
+N > 1: one process per GPU -- started by this script itself (`python bench.py --gpus N`: the parent makes no
+torch / HIP call, spawns the N ranks with the torchrun environment and exits non-zero if any of them fails) or by
+`python -m torch.distributed.run ... bench.py --gpus N` -- games sharded 256/GPU (weak scaling), no data-path
+collective inside the search; training tuples are built on the device (fpc_collect_tuples) and the all-gather
+that ends an episode is one ncclAllGather issued by the engine's C++ host over RCCL/xGMI (fpc_allgather_tuples),
+executed once inside the timed region (the collective only; the records are parsed afterwards, at every N alike).
+A communicator that cannot be set up at --backend nccl stops the job (no silent fallback).
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel group (the MFMA
 implicit-GEMM network forward) with HIP events recorded on the engine's own stream during the
@@ -425,7 +428,7 @@ def main():
     tower_desc = {"k_tower": "k_tower (residual tower megakernel, hidden 128, LDS-resident activations)",
                   "k_tower256": "k_tower256 (residual tower megakernel, hidden 256, LDS-resident activations)",
                   "k_conv3x3": "k_conv3x3 x %d launches (per-layer implicit GEMM, activations through L2) + k_value_tail" % (2 * Nb + 3)}.get(nn_kernel, nn_kernel)
-    fc_kernels = ["k_fc"] + (["k_fc_reduce"] if st.get("fc_reduce_launch", 1) else [])
+    fc_kernels = ["k_fc", "k_fc_reduce"]            # the Linear and its split-K reduce (which also leaves the softmax statistics)
     tree_ms = sel_ms + exp_ms
     label = workload_label(G, sims, Nb, F, R)
     out = {

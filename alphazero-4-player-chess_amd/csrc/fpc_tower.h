@@ -2,10 +2,12 @@
 // head convs, hidden = 128) in ONE launch, one game per workgroup, activations never leaving the CU.
 //
 // Shape of the kernel (gfx950):
-//   * 4 waves = one per SIMD, each with the whole 512-register file: wave (wm, wn) owns MT row tiles
-//     of 16 grid positions x 4 column tiles of 16 output channels (112 x 64 outputs at 14x14) as
-//     v_mfma_f32_16x16x32 accumulators, plus the residual x_l of the same outputs packed in registers.
-//     11 LDS fragment reads feed 28 MFMAs per 32-deep k-step (0.79 KiB of LDS per 32 MFMA cycles).
+//   * 8 waves = two per SIMD, each with half the register file: wave (wm, wn) owns MT row tiles of 16 grid
+//     positions x 2 column tiles of 16 output channels (112 x 32 outputs at 14x14) as v_mfma_f32_16x16x32
+//     accumulators, plus the residual x_l of the same outputs packed in registers.  The two waves of a SIMD (w and
+//     w + 4) have ROLES: the older one carries the whole weight DMA of its pair, the other one passes every tap
+//     barrier three k-steps early, so that one of them always has MFMAs to issue (TW_LOADERS / TW_STAGGER below).
+//     (NW = 4, round 2's one wave per SIMD with 7 x 4 tiles, is kept for same-box A/Bs: FPC_TOWER_WAVES=4.)
 //   * the MFMA is issued as W x X^T: a lane then owns ONE grid position and four consecutive output
 //     channels per accumulator -- one interior predicate and one 8-byte LDS write per tile.
 //   * only tiles that contain interior squares are computed (14 of the 16 grid rows at 14x14).
@@ -14,15 +16,13 @@
 //     16-lane groups each cover all 16 slots of the 256-byte bank row for ANY row shift, so the nine
 //     taps read row-shifted views of one image without bank conflicts.
 //   * weights: one tap = [128 cout][128 cin] = 32 KiB, stored in HBM already in LDS-image order and
-//     brought in by LDS-DMA (global_load_lds_dwordx4, no VGPR hop, no ds_write) into a 3-slot ring, one
-//     tap-time ahead; one barrier per tap publishes it.
+//     brought in by LDS-DMA (global_load_lds_dwordx4, no VGPR hop, no ds_write) into a 3-slot ring;
+//     one barrier per tap publishes it.
 //   * the conv zero padding is the image's zero border; the bottom border row is aliased onto the top
 //     one (row index mod NR), which makes room for the ring in the 160 KiB of LDS.
-//   * one wave per SIMD means every non-MFMA instruction competes with the MFMAs for the SIMD's issue
-//     slots (an MFMA 16x16x32 holds the issue port 8 of its 16 cycles), so the instruction stream is
-//     kept lean: fragment addresses are one VGPR + immediates (14x14: every row tile but the last is a
-//     constant 4 KiB apart), the bias enters as the accumulators' initial value, ReLU runs on packed
-//     16-bit pairs, the DMA uses the SGPR-base form.
+//   * the instruction stream is kept lean: fragment addresses are one VGPR + immediates (14x14: every row
+//     tile but the last is a constant 4 KiB apart), the bias enters as the accumulators' initial value,
+//     ReLU runs on packed 16-bit pairs, the DMA uses the SGPR-base form and (streamed form) immediates.
 #pragma once
 #include <hip/hip_runtime.h>
 

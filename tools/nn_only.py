@@ -5,8 +5,6 @@ HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(HERE, "alphazero-4-player-chess_amd"), HERE]
 import numpy as np, torch
 import fpc_ffi, net, weights
-if os.environ.get('FPC_UNUSED_VARIANT_LIB'):
-    fpc_ffi.LIB_PATH = os.environ['FPC_UNUSED_VARIANT_LIB']   # timing experiments only (tools/var/*.so)
 from bench import Spec
 R, G, iters = 14, 256, int(sys.argv[1]) if len(sys.argv) > 1 else 5
 torch.manual_seed(0)

@@ -81,7 +81,7 @@ struct fpc_engine {
   // back in fpc_search_results, so enabling it does not serialise the pipeline.  Five events per
   // simulation step still cost 2.7 % of the step, so only every TIMING_PERIOD-th step carries them
   // and its intervals are scaled by the period.
-  static constexpr int TIMING_PERIOD = 8;
+  static constexpr int TIMING_PERIOD = 16;   // round 3: at 8 the events still cost 0.3-1.3 % of the step (same-box A/B against --no-stage-timing)
   uint64_t tstep = 0;
   bool tsample = false;
   std::vector<hipEvent_t> evpool;

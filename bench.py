@@ -23,7 +23,7 @@ A communicator that cannot be set up at --backend nccl stops the job (no silent 
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel group (the MFMA
 implicit-GEMM network forward) with HIP events recorded on the engine's own stream during the
-timed steps (every 8th simulation step carries the events; five per step cost 2.7 %); `cpu_baseline`
+timed steps (every 16th simulation step carries the events; on every step the five of them cost 2.7 %); `cpu_baseline`
 times the CPU oracle (oracle/, test infrastructure) + PyTorch-CPU ResNet on a bounded sample of the
 same workload on this box's host cores (N = 1 only).  `value` is measured with the full
 policy head unless --policy-head legal is given (the reference's softmax -> mask -> renormalise arithmetic, op for op); after the timed

@@ -234,7 +234,7 @@ typedef struct fpc_stats {
   /* HIP-event time (events recorded on the engine's stream, resolved in fpc_search_results)
    * accumulated since fpc_stats_reset: select+encode | residual tower incl. head convs |
    * policy Linear (+ split-K reduce) | expand+backup.  Every 16th simulation step is timed and its
-   * intervals count 8x (the events themselves cost time) */
+   * intervals count 16x (the events themselves cost time) */
   double ms_select, ms_tower, ms_fc, ms_expand;
   uint64_t launches_select, launches_nn, launches_expand;
   uint64_t sims;                        /* leaf evaluations + terminal backups */

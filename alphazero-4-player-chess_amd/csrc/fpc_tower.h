@@ -207,7 +207,8 @@ __device__ __forceinline__ void tw_dma_256(const unsigned char *gsrc_uniform, ui
 // Same-box A/B, k_tower per launch, logits bit-identical: S = 0 / 1 / 2 / 3: 0.2874 / 0.2771 / 0.2757 / 0.2653 ms.
 // On top of S = 3, measured and not kept: static s_setprio for either half (0 ... +1.3 %), the burst behind k-step 3
 // instead of behind the barrier (+6 %), and the halves not meeting between layers (the loader half waits for its own
-// four epilogues on an LDS counter and goes on; correct, bit-identical, +0.5 %).
+// four epilogues on an LDS counter and goes on; correct, bit-identical, +0.5 %), and the staggered partner carrying
+// 2 or 4 of its pair's 8 pieces one k-step behind its barrier (+8 % / +7 %).
 #ifndef TW_STAGGER
 #define TW_STAGGER 3
 #endif

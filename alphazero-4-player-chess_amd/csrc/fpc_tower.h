@@ -212,11 +212,6 @@ __device__ __forceinline__ void tw_dma_256(const unsigned char *gsrc_uniform, ui
 #ifndef TW_STAGGER
 #define TW_STAGGER 3
 #endif
-// TW_SPLITDMA = K (staggered build): the staggered partner carries the last K of the 8 pieces of its pair's weight slice,
-// one k-step behind its barrier; the loader's burst shrinks to 8 - K.
-#ifndef TW_SPLITDMA
-#define TW_SPLITDMA 0
-#endif
 
 // NW: waves per workgroup.  4 = one wave per SIMD, wave (wm, wn) owns MT row tiles x 4 column tiles (64 output
 // channels).  8 = two waves per SIMD, each with half the register file: wave (wm, wn) owns MT row tiles x 2 column
@@ -356,34 +351,13 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
                  (uint32_t)__builtin_amdgcn_readfirstlane(TW_BIAS + ((l & 1) * 256 + wave * 64) * 4));
     }
   };
-  constexpr int KSPLIT = (TW_STAGGER == 3 && NW == 8 && TW_LOADERS == 1) ? TW_SPLITDMA : 0;
-  auto burst = [&](int T, auto first_c, auto count_c) {   // pieces [FIRST, FIRST + COUNT) of this pair's 8-KiB slice of tap T, one M0 write
-    constexpr int FIRST = decltype(first_c)::value, COUNT = decltype(count_c)::value;
-    const unsigned char *src = g.Wt + (size_t)T * TW_TAP + (wave & 3) * 8192 + 4096;
-    tw_set_m0((uint32_t)__builtin_amdgcn_readfirstlane(TW_RING + (T % 3) * TW_TAP + (wave & 3) * 8192 + 4096));
-    if (FIRST <= 0 && 0 < FIRST + COUNT) tw_dma_piece<-4096>(src, dma_lane);
-    if (FIRST <= 1 && 1 < FIRST + COUNT) tw_dma_piece<-3072>(src, dma_lane);
-    if (FIRST <= 2 && 2 < FIRST + COUNT) tw_dma_piece<-2048>(src, dma_lane);
-    if (FIRST <= 3 && 3 < FIRST + COUNT) tw_dma_piece<-1024>(src, dma_lane);
-    if (FIRST <= 4 && 4 < FIRST + COUNT) tw_dma_piece<0>(src, dma_lane);
-    if (FIRST <= 5 && 5 < FIRST + COUNT) tw_dma_piece<1024>(src, dma_lane);
-    if (FIRST <= 6 && 6 < FIRST + COUNT) tw_dma_piece<2048>(src, dma_lane);
-    if (FIRST <= 7 && 7 < FIRST + COUNT) tw_dma_piece<3072>(src, dma_lane);
-  };
   auto issue_tap = [&](int T) {   // the whole tap T -> ring slot T % 3 in one burst
     issue_bias(T);
-    if (KSPLIT != 0) {
-      if (LOAD != 0) burst(T, std::integral_constant<int, 0>{}, std::integral_constant<int, 8 - KSPLIT>{});
-      return;
-    }
     if (LOAD == 0) return;
     const unsigned char *src = g.Wt + (size_t)T * TW_TAP + lw * DMA_PER_WAVE;
     const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(TW_RING + (T % 3) * TW_TAP + lw * DMA_PER_WAVE);   // smem starts at LDS byte 0
     if (PIECES == 8) tw_dma_8k(src, dma_lane, dst);
     else tw_dma_4k(src, dma_lane, dst);
-  };
-  auto partner_issue = [&](int T) {                // the staggered partner's share of tap T
-    if (KSPLIT != 0 && LOAD == 0 && T < total) burst(T, std::integral_constant<int, 8 - KSPLIT>{}, std::integral_constant<int, KSPLIT>{});
   };
   // TW_AHEAD 2: the stream.  open_tap(T) right behind a tap barrier (no LDS read in flight): M0 and the source
   // base of tap T; piece<I>() anywhere after that.
@@ -400,8 +374,6 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
   };
   issue_tap(0);
   issue_tap(1);
-  partner_issue(0);
-  partner_issue(1);
   if (STREAM) {                                    // first quarter of tap 2; the k-steps carry on from there
     open_tap(2);
     piece(std::integral_constant<int, 0>{});
@@ -524,12 +496,8 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
 #pragma unroll
       for (int ct = 0; ct < (MODE == 0 ? CT : 1); ++ct) b4[ct] = *reinterpret_cast<const t_f32x4 *>(bl + ct * 16);
     }
-    if (STAG == 3) {
-      if (KSPLIT != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
+    if (STAG == 3) __syncthreads();                // (a staggered wave issued no DMA: nothing to wait for)
     kstep(mode_c, c0, c1, c1, b4, c1);             // (tap 0, k-step 0), C = bias
-    if (STAG == 3) partner_issue(gt + 2);
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
       if (STAG == 2) {
@@ -563,12 +531,8 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
       TW_STAMP(gt - 1, 6);
       kstep(mode_c, c1, c0, c0, b4, c0);           // k-step 3, reading (next tap, k-step 0)
       TW_STAMP(gt - 1, 7);
-      if (STAG == 3 && tap < 8) {
-        if (KSPLIT != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-      }
+      if (STAG == 3 && tap < 8) __syncthreads();
       if (tap < 8) kstep(mode_c, c0, c1, c0, b4, c1);  // (next tap, k-step 0)
-      if (STAG == 3 && tap < 8) partner_issue(gt + 2);
       TW_STAMP(gt - 1, 8);
     }
   };

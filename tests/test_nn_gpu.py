@@ -108,6 +108,34 @@ def test_resnet_forward_vs_torch_fp32(R, blocks, hidden, dtype, tol):
     eng.close()
 
 
+@pytest.mark.parametrize("R,blocks", [(14, 3), (8, 3), (10, 2), (13, 2)])
+def test_tower_wave_forms_give_identical_bits(R, blocks, monkeypatch):
+    """k_tower on 8 waves (two per SIMD, loader / staggered roles, the default) and on 4 waves (round 2's form with the
+    streamed weight DMA; developer knob FPC_TOWER_WAVES=4) run the same MFMAs on the same operands in the same order
+    per output element: logits and values must agree BIT FOR BIT, for both operand types."""
+    import torch
+    import weights
+    m = _model(R, blocks, 128, seed=5)
+    G = 48
+    x = (torch.rand(G, 24, R, R, generator=torch.Generator().manual_seed(R)) < 0.1).float().cuda()
+    for dtype in (1, 0):
+        outs = []
+        for waves in ("8", "4"):
+            monkeypatch.setenv("FPC_TOWER_WAVES", waves)
+            eng = make_engine("gpu", R, INV_OF[R], max_games=G, max_sims=4, nn_dtype=dtype)
+            eng.load_weights(weights.export_weights(m, dtype))
+            lg = torch.empty(G, eng.A, device="cuda")
+            va = torch.empty(G, device="cuda")
+            for _ in range(3):
+                eng.nn_forward(x.data_ptr(), G, lg.data_ptr(), va.data_ptr())
+            torch.cuda.synchronize()
+            outs.append((lg.cpu().numpy().copy(), va.cpu().numpy().copy()))
+            eng.close()
+        monkeypatch.delenv("FPC_TOWER_WAVES")
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), (R, dtype)
+        assert np.abs(outs[0][0]).mean() > 1e-3
+
+
 def test_resnet_forward_more_than_256_rows():
     """300 positions = two 256-row tiles of the policy Linear (blockIdx.y, plan_fc with two passes of
     blocks) and 150 tower blocks of two 8x8 games each; same bound as the single-tile cases."""

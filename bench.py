@@ -75,19 +75,22 @@ class Spec:
 
 
 def pick_moves(res, rng, temperature):
-    """alphazero.py:104-119: pi ~ child visit counts, temperature, multinomial (seeded here)."""
-    G = len(res["n_children"])
-    flats = np.zeros(G, np.int64)
-    for g in range(G):
-        n = int(res["n_children"][g])
-        if n == 0:
-            flats[g] = -1
-            continue
-        p = res["visits"][g, :n].astype(np.float64)
-        p /= p.sum()
-        p = p ** (1.0 / temperature)
-        p /= p.sum()
-        flats[g] = res["flat"][g, rng.choice(n, p=p)]
+    """alphazero.py:104-119: pi ~ child visit counts, temperature, one multinomial draw per game (seeded here;
+    all games at once: the per-game Python loop cost 2 ms of host time per ply)."""
+    n = np.asarray(res["n_children"]).astype(np.int64)
+    G = len(n)
+    width = max(int(n.max()), 1)
+    live = np.arange(width)[None, :] < n[:, None]
+    p = np.where(live, res["visits"][:, :width].astype(np.float64), 0.0)
+    tot = p.sum(axis=1, keepdims=True)
+    p = np.divide(p, tot, out=np.zeros_like(p), where=tot > 0)
+    p = np.where(live, p ** (1.0 / temperature), 0.0)
+    tot = p.sum(axis=1, keepdims=True)
+    p = np.divide(p, tot, out=np.zeros_like(p), where=tot > 0)
+    idx = (np.cumsum(p, axis=1) < rng.random(G)[:, None]).sum(axis=1)
+    idx = np.minimum(idx, np.maximum(n - 1, 0))
+    flats = np.asarray(res["flat"])[np.arange(G), idx].astype(np.int64)
+    flats[n == 0] = -1
     return flats
 
 

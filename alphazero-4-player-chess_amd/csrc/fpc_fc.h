@@ -1,4 +1,4 @@
-// fpc_fc.h -- k_fc: the policy Linear (net.py:25: A -> A, 553 M weights at 14x14 = 1.1 GB in 16 bit)
+// fpc_fc.h -- k_fc / k_fc16: the policy Linear (net.py:25: A -> A, 553 M weights at 14x14 = 1.1 GB in 16 bit)
 // as a weight-streaming GEMM for M = 256 rows: every weight byte is used once per forward, so the
 // kernel is bound by the HBM stream (1.11 GB per launch; 283 GFLOP ride on it).
 //
@@ -32,6 +32,8 @@
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
+
+#include "fpc_tower.h"   // M16: the 16x16x32 MFMA wrappers
 
 namespace fpc {
 
@@ -219,6 +221,136 @@ __global__ void __launch_bounds__(FC_THREADS, 1) k_fc(FcArgs g) {
         out[(long)m * 256 + col] = acc[t][n][r];
       }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_fc16: the same Linear on v_mfma_f32_16x16x32 (the shape the chip holds the higher clock on under load,
+// MI355X_MICROARCH.md "DVFS give-back" item 7; k_tower uses it for the same reason).  Same decomposition, same
+// LDS map, same two DMA streams two stages ahead, same bytes of LDS read per FLOP (20 fragment reads per 1 024
+// matrix-pipe cycles).  What differs:
+//   * the product is issued as W x X^T: a lane owns ONE activation row and four consecutive output columns per
+//     accumulator, so a partial tile goes out as one 16-byte store per lane (64 stores per wave instead of 256);
+//   * the weight fragment order is [k-step of 32][column tile of 16][lane = 16 q + c][8]:
+//     element (k32, nt, q, c, e) = W'[16 nt + c][32 k32 + 8 q + e]  (weights.py writes it; blob header fc_layout = 1);
+//   * a k-step is 32 deep: 64 MFMAs on 16 activation fragments x 4 weight fragments; 8 DMA pieces per k-step in the
+//     fixed order  X, W, W, X, X, W, W, X  (the weight pieces in pairs behind one M0 write).  Counted waits:
+//     first k-step of a stage: the weights of its second k-step were issued three k-steps ago; behind their last
+//     piece came 1 + 8 + 8 pieces -> vmcnt(17); second k-step: the activations of the next stage (last piece: two
+//     k-steps ago) and everything older -> vmcnt(8), then THE stage barrier.
+template <int DT>
+__global__ void __launch_bounds__(FC_THREADS, 1) k_fc16(FcArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [3 X buffers][4 per-wave weight rings]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nbig = g.G1 * g.s1;
+  const int id = blockIdx.x;
+  const bool big = id < nbig;
+  const int idr = big ? id : id - nbig;
+  const int sk = big ? g.s1 : g.s2;
+  const int group = big ? idr / sk : g.G1 + idr / sk;
+  const int split = idr % sk;
+  const int ntile = group * 16 + wave * 4;        // this wave's four 16-column tiles
+  const int KS = g.ksteps / sk;                   // k-steps of 16 handled by this block; multiple of 8
+  const int ks0 = split * KS;
+  const int S = KS / 4;                           // stages of BK = 64 (even, >= 4)
+  const long mrow0 = (long)blockIdx.y * 256;
+  // weight stream of this wave: fragment (k32-step k, tile ntile + n) = 1 KiB at wbase + (k * Np/16 + n) KiB
+  const unsigned char *wbase = reinterpret_cast<const unsigned char *>(g.Wf) + ((long)(ks0 / 2) * (g.Np / 16) + ntile) * 1024;
+  const long wk32 = (long)(g.Np / 16) * 1024;
+  const uint32_t wlane = (uint32_t)lane * 16u;
+  const unsigned char *xbase = reinterpret_cast<const unsigned char *>(g.X) + ((mrow0 + wave * 64) * g.Kp + (long)ks0 * 16) * 2;
+  const long xpiece = 8L * g.Kp * 2;
+  uint32_t xlane[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int j = (lane & 7) ^ ((par * 4 + (lane >> 4)) & 7);
+    xlane[par] = (uint32_t)((lane >> 3) * g.Kp * 2 + j * 16);
+  }
+  const uint32_t lds_x = 0, lds_w = (uint32_t)(3 * FC_XBUF + wave * FC_WRING);
+  const unsigned char *wr = smem + 3 * FC_XBUF + wave * FC_WRING + lane * 16;
+
+  f32x4_t acc[16][4];
+  u32x4_t xf[2][16], wf[2][4];
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  const std::integral_constant<int, 0> c0{};
+  const std::integral_constant<int, 1> c1{};
+
+  auto issue_x = [&](int s, int p) {              // piece p (8 rows) of activation stage s
+    const int sc = s < S ? s : S - 1;
+    fc_dma(xbase + (long)p * xpiece + (long)sc * 128, xlane[p & 1],
+           (uint32_t)__builtin_amdgcn_readfirstlane(lds_x + (s % 3) * FC_XBUF + (wave * 64 + p * 8) * 128));
+  };
+  auto issue_w2 = [&](int s, int j, int n0) {      // column tiles n0, n0 + 1 of k32-step j of stage s
+    const int sc = s < S ? s : S - 1;
+    fc_dma2_nt(wbase + (long)(2 * sc + j) * wk32 + n0 * 1024, wlane,
+               (uint32_t)__builtin_amdgcn_readfirstlane(lds_w + ((s & 1) * 8 + j * 4 + n0) * 1024));
+  };
+  auto xfrag = [&](int b, int t, const unsigned char *ab, int j) {
+    xf[b][t] = *reinterpret_cast<const u32x4_t *>(ab + lds_off<64>(t * 16 + (lane & 15), j * 4 + (lane >> 4)));
+  };
+  auto wfrag = [&](int b, int s, int j) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) wf[b][n] = *reinterpret_cast<const u32x4_t *>(wr + ((s & 1) * 8 + j * 4 + n) * 1024);
+  };
+  auto kstep = [&](auto j_c, auto z_c, int s) {
+    constexpr int J = decltype(j_c)::value;
+    constexpr bool Z = decltype(z_c)::value != 0;
+    constexpr int CUR = J, NXT = J ^ 1;
+    if (J == 0) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+    if (J == 1) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); __syncthreads(); }
+    const unsigned char *ab = smem + ((J == 1 ? s + 1 : s) % 3) * FC_XBUF;
+    constexpr int JN = J ^ 1;
+    __builtin_amdgcn_sched_barrier(0);
+    wfrag(NXT, J == 1 ? s + 1 : s, JN);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[t][n] = M16<DT>::mfma(wf[CUR][n], xf[CUR][t], Z ? zero4 : acc[t][n]);
+      __builtin_amdgcn_sched_barrier(0);
+      xfrag(NXT, t, ab, JN);
+      if (t == 1) issue_x(s + 2, J * 4 + 0);
+      if (t == 5) issue_w2(s + 2, J, 0);
+      if (t == 7) issue_x(s + 2, J * 4 + 1);
+      if (t == 9) issue_x(s + 2, J * 4 + 2);
+      if (t == 13) issue_w2(s + 2, J, 2);
+      if (t == 15) issue_x(s + 2, J * 4 + 3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // prologue: stages 0 and 1 of both streams, then the fragments of (0, 0)
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) issue_x(st, p);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { issue_w2(st, j, 0); issue_w2(st, j, 2); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 16; ++t) xfrag(0, t, smem, 0);
+  wfrag(0, 0, 0);
+
+  kstep(c0, c1, 0);                               // (0, 0): C = 0
+  kstep(c1, c0, 0);
+#pragma unroll 1
+  for (int s = 1; s < S; ++s) {
+    kstep(c0, c0, s);
+    kstep(c1, c0, s);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail pieces: nothing may still target LDS at exit
+
+  const int slab = big ? id : nbig + idr;
+  float *out = g.part + ((long)slab * g.Mtot + mrow0) * 256;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int m = t * 16 + (lane & 15);
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+      *reinterpret_cast<f32x4_t *>(out + (long)m * 256 + wave * 64 + n * 16 + (lane >> 4) * 4) = acc[t][n];
+  }
 }
 
 // logits[m][n] = bias[n] + slab[base][m][n%256] + slab[base+1][m][n%256] + ...   (fixed order)

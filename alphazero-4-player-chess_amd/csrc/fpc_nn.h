@@ -263,14 +263,16 @@ namespace fpc {
 // shares (a game with 90 legal moves does not hold one CU three times longer than one with 30).
 // ================================================================================================
 template <int DT>
-__global__ void __launch_bounds__(256) k_fc_unfrag(const uint16_t *Wf, uint16_t *W2, int Np, int Kp) {
+__global__ void __launch_bounds__(256) k_fc_unfrag(const uint16_t *Wf, uint16_t *W2, int Np, int Kp, int layout) {
   // one thread per 16-byte chunk of the row-major matrix: (n, k8) <- fragment order [ks][nt][lane][8]
+  // (layout 0: k-steps of 16, tiles of 32 columns, lane = 32 h + r; layout 1: k-steps of 32, tiles of 16, lane = 16 q + c)
   const long c = (long)blockIdx.x * 256 + threadIdx.x;
   const long chunks = (long)Np * (Kp / 8);
   if (c >= chunks) return;
   const int n = (int)(c / (Kp / 8)), k8 = (int)(c % (Kp / 8));
   const int ks = k8 >> 1, h = k8 & 1, nt = n >> 5, n32 = n & 31;
-  const long src = (((long)ks * (Np / 32) + nt) * 64 + (h * 32 + n32)) * 8;
+  const long src = layout == 0 ? (((long)ks * (Np / 32) + nt) * 64 + (h * 32 + n32)) * 8
+                               : (((long)(k8 >> 2) * (Np / 16) + (n >> 4)) * 64 + ((k8 & 3) * 16 + (n & 15))) * 8;
   *reinterpret_cast<u32x4_t *>(W2 + (long)n * Kp + (long)k8 * 8) = *reinterpret_cast<const u32x4_t *>(Wf + src);
 }
 
@@ -402,7 +404,8 @@ __global__ void __launch_bounds__(64) k_nchw_to_grid(const float *x, int n, int 
 struct BlobHeader {
   char magic[4];
   int32_t version, R, F, nblocks, dtype, A_ch, Np, Kp;
-  int32_t pad[7];
+  int32_t fc_layout;     // fragment order of the policy Linear's weights: 0 = 32x32x16 (k_fc), 1 = 16x16x32 (k_fc16)
+  int32_t pad[6];
 };
 static_assert(sizeof(BlobHeader) == 64, "header is 64 bytes");
 
@@ -431,6 +434,7 @@ struct NN {
   float *fcb = nullptr, *vw = nullptr;
   float *fc_part = nullptr;      // [slabs][Gpad][256] partial sums of k_fc (sized for 2*FC_SPLITK slabs per group)
   int fc_G1 = 0, fc_s2 = FC_SPLITK;   // work decomposition chosen at load time (plan_fc)
+  int fc_layout = 0;                 // the loaded blob's weight fragment order: 0 -> k_fc, 1 -> k_fc16
   unsigned char *towerW = nullptr;   // k_tower's weight stream: [(2*nblocks + 2) * 9 taps][32 KiB] in LDS-image order (F == 128)
   unsigned char *stemW = nullptr;    // [9 taps][8 KiB], same order
   float *towerB = nullptr;           // [2*nblocks + 2][256] (128 used)
@@ -521,6 +525,8 @@ struct NN {
     }
     destroy();
     F = h.F; nblocks = h.nblocks; Np = h.Np; Kp = h.Kp;
+    if (h.fc_layout != 0 && h.fc_layout != 1) { *err = "unknown policy-Linear weight layout in weight blob"; return FPC_EWEIGHTS; }
+    fc_layout = h.fc_layout;
     const unsigned char *base = (const unsigned char *)blob;
     uint64_t off = sizeof(BlobHeader);
     int rc = 0;
@@ -716,8 +722,13 @@ struct NN {
       const int mtiles = (n + 255) / 256;
       const int blocks = fc_G1 * FC_SPLITK + (Np / 256 - fc_G1) * fc_s2;
       bool &fattr = attr_fc[DT];
-      if (!fattr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fc<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS); fattr = true; }
-      hipLaunchKernelGGL((k_fc<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), FC_LDS, stream, f);
+      if (!fattr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fc<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fc16<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS);
+        fattr = true;
+      }
+      if (fc_layout == 1) hipLaunchKernelGGL((k_fc16<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), FC_LDS, stream, f);
+      else hipLaunchKernelGGL((k_fc<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), FC_LDS, stream, f);
       hipLaunchKernelGGL(k_fc_reduce, dim3((dc.A / 4 + 255) / 256, n), dim3(256), 0, stream, (const float *)fc_part, (const float *)fcb,
                          fc_G1, FC_SPLITK, fc_s2, Gpad, dc.A, n, logits_out, d_stats);
       const hipError_t le = hipGetLastError();
@@ -740,8 +751,8 @@ struct NN {
     int rc;
     if ((rc = dmalloc(&fcw2, (size_t)Np * Kp, err)) || (rc = dmalloc(&d_ll, (size_t)Gmax * FPC_MAX_MOVES, err))) return rc;
     const long chunks = (long)Np * (Kp / 8);
-    if (dtype) hipLaunchKernelGGL((k_fc_unfrag<1>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)fcw, fcw2, Np, Kp);
-    else hipLaunchKernelGGL((k_fc_unfrag<0>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)fcw, fcw2, Np, Kp);
+    if (dtype) hipLaunchKernelGGL((k_fc_unfrag<1>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)fcw, fcw2, Np, Kp, fc_layout);
+    else hipLaunchKernelGGL((k_fc_unfrag<0>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)fcw, fcw2, Np, Kp, fc_layout);
     if (hipGetLastError() != hipSuccess) { *err = "k_fc_unfrag launch failed"; return FPC_ENODEVICE; }
     return 0;
   }

@@ -6,6 +6,7 @@ torch.no_grad(), alphazero.py:262 / mcts.py:15):   w' = w * g/sqrt(var+eps),  b'
 Conv weights go to [tap][Cout_pad][Cin_pad] (K contiguous); the policy Linear's input axis is
 permuted from the reference's NCHW flatten (ch*R*R + pos) to the engine's NHWC flatten
 (pos*A_ch + ch) and both axes are zero-padded to tile multiples."""
+import os
 import struct
 
 import numpy as np
@@ -40,8 +41,12 @@ def _conv_section(w, b, cin_pad, cout_pad, dtype):
     return [_to16(wt, dtype), bb.numpy().astype(np.float32).tobytes()]
 
 
-def export_weights(model, dtype=0):
+FC_LAYOUT = int(os.environ.get("FPC_FC_LAYOUT", "1"))      # 1: 16x16x32 fragment order (k_fc16, default); 0: 32x32x16 (k_fc)
+
+
+def export_weights(model, dtype=0, fc_layout=None):
     """model: ResNet in eval semantics.  dtype 0 = bf16, 1 = fp16.  Returns bytes."""
+    fc_layout = FC_LAYOUT if fc_layout is None else int(fc_layout)
     F = model.startBlock[0].weight.shape[0]
     nblocks = len(model.backBone)
     A_ch = model.policyHead[0].weight.shape[0]
@@ -71,9 +76,14 @@ def export_weights(model, dtype=0):
     fwp = torch.zeros(Np, Kp, dtype=t16)
     fwp[:A, :A] = fw.to(t16)
     del fw
-    # MFMA fragment order (csrc/fpc_nn.h k_fc): [kstep16][n_tile32][lane = 32*h + r][8],
-    # element (ks, nt, h, r, e) = W'[nt*32 + r][ks*16 + h*8 + e]
-    wf = fwp.view(Np // 32, 32, Kp // 16, 2, 8).permute(2, 0, 3, 1, 4).contiguous()
+    if fc_layout == 0:
+        # MFMA fragment order of k_fc (32x32x16): [kstep16][n_tile32][lane = 32*h + r][8],
+        # element (ks, nt, h, r, e) = W'[nt*32 + r][ks*16 + h*8 + e]
+        wf = fwp.view(Np // 32, 32, Kp // 16, 2, 8).permute(2, 0, 3, 1, 4).contiguous()
+    else:
+        # MFMA fragment order of k_fc16 (16x16x32): [kstep32][n_tile16][lane = 16*q + c][8],
+        # element (ks, nt, q, c, e) = W'[nt*16 + c][ks*32 + q*8 + e]
+        wf = fwp.view(Np // 16, 16, Kp // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
     del fwp
     secs.append(wf.view(torch.int16).numpy().tobytes())
     del wf
@@ -85,7 +95,7 @@ def export_weights(model, dtype=0):
     vw[:, :24] = _cpu(vfc.weight).view(24, RR).t()
     secs.append(vw.numpy().astype(np.float32).tobytes())
     secs.append(struct.pack("<f", float(_cpu(vfc.bias).item())))
-    out = bytearray(struct.pack("<4s8i28x", b"FPCW", 2, R, F, nblocks, dtype, A_ch, Np, Kp))
+    out = bytearray(struct.pack("<4s9i24x", b"FPCW", 2, R, F, nblocks, dtype, A_ch, Np, Kp, fc_layout))
     assert len(out) == 64
     for s in secs:
         out += b"\0" * ((-len(out)) % 64)

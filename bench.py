@@ -431,7 +431,7 @@ def main():
     tower_desc = {"k_tower": "k_tower (residual tower megakernel, hidden 128, LDS-resident activations)",
                   "k_tower256": "k_tower256 (residual tower megakernel, hidden 256, LDS-resident activations)",
                   "k_conv3x3": "k_conv3x3 x %d launches (per-layer implicit GEMM, activations through L2) + k_value_tail" % (2 * Nb + 3)}.get(nn_kernel, nn_kernel)
-    fc_kernels = ["k_fc", "k_fc_reduce"]            # the Linear and its split-K reduce (which also leaves the softmax statistics)
+    fc_kernels = ["k_fc16" if weights.FC_LAYOUT == 1 else "k_fc", "k_fc_reduce"]   # the Linear (by the weight layout exported) and its split-K reduce
     tree_ms = sel_ms + exp_ms
     label = workload_label(G, sims, Nb, F, R)
     out = {

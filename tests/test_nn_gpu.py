@@ -136,6 +136,34 @@ def test_tower_wave_forms_give_identical_bits(R, blocks, monkeypatch):
         assert np.abs(outs[0][0]).mean() > 1e-3
 
 
+@pytest.mark.parametrize("R,dtype", [(14, 1), (8, 0)])
+def test_both_policy_linear_kernels_meet_the_fp32_network(R, dtype):
+    """k_fc16 (16x16x32, [k32][tile16] weight order: the default) and k_fc (32x32x16, fc_layout = 0 in the blob):
+    each within the operand type's bound of the fp32 torch network, and within rounding of each other."""
+    import torch
+    import weights
+    m = _model(R, 2, 128, seed=9)
+    boards = _positions(R, 24)
+    outs = []
+    for layout in (1, 0):
+        eng = make_engine("gpu", R, INV_OF[R], max_games=len(boards), max_sims=4, nn_dtype=dtype)
+        eng.load_weights(weights.export_weights(m, dtype, fc_layout=layout))
+        enc = np.concatenate([eng.encode([b]) for b in boards])
+        x = torch.from_numpy(enc).cuda()
+        lg = torch.empty(len(boards), eng.A, device="cuda")
+        va = torch.empty(len(boards), device="cuda")
+        eng.nn_forward(x.data_ptr(), len(boards), lg.data_ptr(), va.data_ptr())
+        torch.cuda.synchronize()
+        outs.append(lg.cpu().numpy().copy())
+        eng.close()
+    with torch.no_grad():
+        ref_l, _ = m(torch.from_numpy(enc))
+    tol = 1e-3 if dtype else 8e-3
+    for o in outs:
+        assert np.abs(o - ref_l.numpy()).max() < tol
+    assert np.abs(outs[0] - outs[1]).max() < 2e-5      # same operands, f32 accumulation in another order
+
+
 def test_resnet_forward_more_than_256_rows():
     """300 positions = two 256-row tiles of the policy Linear (blockIdx.y, plan_fc with two passes of
     blocks) and 150 tower blocks of two 8x8 games each; same bound as the single-tile cases."""

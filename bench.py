@@ -540,7 +540,7 @@ def cpu_baseline(R, INV, model, args):
     cores = host_cores()
     torch.set_num_threads(cores)
     turn, entries = positions.start_entries(R)
-    Gc, sc = 16, 100
+    Gc, sc = 16, 200      # about 15 s of CPU work on the GPU box's 16 host cores (bounded sample of the same workload)
     boards = [orc.board_from_dict(R, turn, [list(e) for e in entries]) for _ in range(Gc)]
 
     def ev(enc):

@@ -47,13 +47,13 @@ class AlphaZero:
         def search_fn(pods):
             boards = [self.gameType._wrap(p) for p in pods]
             roots = self.mcts.search(boards)
-            n = max(len(r._children) for r in roots)
-            res = {"n_children": np.array([len(r._children) for r in roots]),
+            arrs = [r.child_arrays() for r in roots]                 # no Python object per child
+            n = max(len(f) for f, _ in arrs)
+            res = {"n_children": np.array([len(f) for f, _ in arrs]),
                    "flat": np.zeros((len(roots), n), np.int64), "visits": np.zeros((len(roots), n), np.int64)}
-            for i, r in enumerate(roots):
-                for k, c in enumerate(r._children):
-                    res["flat"][i, k] = c.GetMoveMade().GetFlatIndex()
-                    res["visits"][i, k] = c.GetVisitCount()
+            for i, (f, v) in enumerate(arrs):
+                res["flat"][i, :len(f)] = f
+                res["visits"][i, :len(v)] = v
             return res
 
         episodes = selfplay.play(search_fn, eng, [g._b for g in games], self.args, uniforms)

@@ -267,35 +267,65 @@ class PlacedPiece:                      # engine/board.h:446-471, wrapper.cpp:12
 
 
 class Move:                             # move.h:23-49, move.cpp:23-104, wrapper.cpp:135-163
+    _flat = None        # Move(flat_index) keeps the index; from / to are decoded when somebody asks (move.cpp:39-61)
+    _capture = None
+    _promo = PieceType.NO_PIECE
+
     def __init__(self, *a, **kw):
-        self._from, self._to = BoardLocation(), BoardLocation()
-        self._capture, self._promo = Piece(), PieceType.NO_PIECE
         if kw:
             a = tuple(a) + tuple(kw[k] for k in ("flat_index", "action_plane", "from", "c_move", "to") if k in kw)
         if len(a) == 0:
+            self._ft = (BoardLocation(), BoardLocation())
             return
         if len(a) == 1 and isinstance(a[0], Move):
             o = a[0]
-            self._from, self._to, self._capture, self._promo = o._from, o._to, o._capture, o._promo
+            self._flat, self._capture, self._promo = o._flat, o._capture, o._promo
+            if o._flat is None:
+                self._ft = (o._from, o._to)
         elif len(a) == 1:                                   # Move(flat_index), move.cpp:39-61
-            import ctypes as C
-            f, t = C.c_int(), C.c_int()
             flat = int(a[0])
             if flat < 0 or flat >= Board.action_space_size:
                 raise RuntimeError("flat index out of range")
-            _ffi.lib().fpc_flat_to_move(_R, flat, C.byref(f), C.byref(t))
-            self._from, self._to = BoardLocation._from_sq(f.value), BoardLocation._from_sq(t.value)
+            self._flat = flat
         elif len(a) == 2 and isinstance(a[1], BoardLocation) and not isinstance(a[0], BoardLocation):
             frm = a[1]                                      # Move(action_plane, from), move.cpp:23-37
             flat = int(a[0]) * _R * _R + frm.GetRow() * _R + frm.GetCol()
-            m = Move(flat)
-            self._from, self._to = frm, m._to
+            if flat < 0 or flat >= Board.action_space_size:
+                raise RuntimeError("flat index out of range")
+            self._flat = flat
         else:                                               # standard / pawn-move constructors
-            self._from, self._to = a[0], a[1]
+            self._ft = (a[0], a[1])
             if len(a) > 2 and isinstance(a[2], Piece):
                 self._capture = a[2]
             if len(a) == 6:
                 self._promo = PieceType(int(a[5]))
+
+    def _ends(self):
+        e = self.__dict__.get("_ft")
+        if e is None:
+            import ctypes as C
+            f, t = C.c_int(), C.c_int()
+            _ffi.lib().fpc_flat_to_move(_R, int(self._flat), C.byref(f), C.byref(t))
+            e = self.__dict__["_ft"] = (BoardLocation._from_sq(f.value), BoardLocation._from_sq(t.value))
+        return e
+
+    @property
+    def _from(self):
+        return self._ends()[0]
+
+    @_from.setter
+    def _from(self, v):
+        self.__dict__["_ft"] = (v, self._ends()[1])
+        self._flat = None
+
+    @property
+    def _to(self):
+        return self._ends()[1]
+
+    @_to.setter
+    def _to(self, v):
+        self.__dict__["_ft"] = (self._ends()[0], v)
+        self._flat = None
 
     def From(self):
         return self._from
@@ -308,8 +338,10 @@ class Move:                             # move.h:23-49, move.cpp:23-104, wrapper
         return (flat // (_R * _R), self._from.GetRow(), self._from.GetCol())
 
     def GetFlatIndex(self):
-        flat = _ffi.lib().fpc_move_flat_index(_R, self._from._sq(), self._to._sq()) if (
-            self._from.Present() and self._to.Present()) else -1
+        if self._flat is not None:
+            return self._flat
+        f, t = self._ends()
+        flat = _ffi.lib().fpc_move_flat_index(_R, f._sq(), t._sq()) if (f.Present() and t.Present()) else -1
         if flat < 0:
             raise RuntimeError("Invalid move: No corresponding action plane index found. Did you initialize move_index_map?")
         return flat
@@ -338,6 +370,9 @@ class Node:
     encode, legal moves) still goes through the engine's C-ABI.  It is the compatibility path, orders of
     magnitude slower than MCTS.search, and never used by it."""
 
+    _batch = None       # roots returned by MCTS.search: the _SearchBatch whose arrays hold their children ...
+    _g = 0              # ... and the game's row in them
+
     def __init__(self, C=0.0, state=None, parent=None, action_taken=None, prior=0.0, visit_count=0):
         self._C, self._state, self._parent, self._move = C, state, parent, action_taken
         self._prior, self._n, self._children = prior, visit_count, []
@@ -350,7 +385,33 @@ class Node:
     def GetState(self):
         return self._state
 
+    def _materialise(self):
+        """a search root's child views are made the first time somebody asks for them (a search over 256 games
+        returns ~6 000 root children; callers that read the arrays -- child_arrays() -- never pay for objects)"""
+        b = self._batch
+        if b is not None and not self._children:
+            self._children = b.child_views(self)
+        return self._children
+
+    def child_arrays(self):
+        """(flat index, visit count) of this node's children as two int arrays, ascending flat index -- what
+        alphazero.py:104-110 builds pi from -- without creating a Python object per child"""
+        b = self._batch
+        if b is not None:
+            n = int(b.res["n_children"][self._g])
+            return b.res["flat"][self._g, :n], b.res["visits"][self._g, :n]
+        import numpy as np
+        kids = self.GetChildren()
+        return (np.array([c.GetMoveMade().GetFlatIndex() for c in kids], np.int32),
+                np.array([c.GetVisitCount() for c in kids], np.int32))
+
+    def n_children(self):
+        b = self._batch
+        return int(b.res["n_children"][self._g]) if b is not None else len(self.GetChildren())
+
     def GetChildren(self):
+        if self._batch is not None:
+            return list(self._materialise())
         if self._lazy is not None:
             eng, game, idx = self._lazy
             self._lazy = None
@@ -437,8 +498,120 @@ class Node:
                 node._children.append(Node(node._C, child_state, node, mv, prob, 1))
 
 
+class _RootChild(Node, Move):
+    """Read-only view of ONE child of a search root (MCTS.search keeps the tree on the GPU): the Node read API
+    the training loop uses (GetMoveMade / GetVisitCount / GetChildren / GetState / IsExpanded, alphazero.py:104-110)
+    over the search's result arrays.  It is also its own `Move` -- GetMoveMade() returns the view itself, which
+    answers GetFlatIndex / GetIndex / From / To -- so that reading a child costs one small object, not a Node, a Move
+    and two BoardLocations (6 000 root children per ply at 256 games)."""
+    __slots__ = ("_flat", "_n", "_k", "_parent")
+    _state = None
+    _lazy = None
+    _batch = None
+
+    def __init__(self, flat, n, k, parent):
+        self._flat, self._n, self._k, self._parent = flat, n, k, parent
+
+    # -- Node side
+    def GetMoveMade(self):
+        return self
+
+    def GetChildren(self):
+        kids = self.__dict__.get("_kids")
+        if kids is None:
+            b = self._parent._batch
+            kids = [Node(self._parent._C, None, self, Move(fl), 0.0, n) for fl, n in b.eng.grandchildren(self._parent._g, self._k)]
+            self.__dict__["_kids"] = kids
+        return list(kids)
+
+    @property
+    def _children(self):
+        return self.GetChildren()
+
+    @property
+    def _C(self):
+        return self._parent._C
+
+    @property
+    def _move(self):
+        return self
+
+    @property
+    def _prior(self):
+        return float(self._parent._batch.res["prior"][self._parent._g, self._k])
+
+    @property
+    def _value_sum(self):
+        return float(self._parent._batch.res["w"][self._parent._g, self._k])
+
+    def _host_only(self):
+        raise RuntimeError("this node is a read-only view of a tree that lives on the GPU (MCTS.search): it has no "
+                           "state to descend into; build host nodes with Node(C, state, ...)")
+
+    def SelectChild(self):
+        self._host_only()
+
+    def Backpropagate(self, value):
+        self._host_only()
+
+    # -- Move side (move.cpp:39-61: a move rebuilt from its flat index has from / to only, Q9)
+    def GetFlatIndex(self):
+        return self._flat
+
+    def __repr__(self):
+        return "Node(move %d, N=%d)" % (self._flat, self._n)
+
+
+class _SearchBatch:
+    """What one MCTS.search call left behind: the engine's result arrays for all its games (root children as
+    [G, max_children] arrays) and, made on first use, the successor position of EVERY root child with its game result
+    -- one batched TakeAction and one batched GetGameResult for the whole search instead of two synchronous GPU round
+    trips per game (alphazero.py:119-123 calls state.TakeAction(action) and next_state.GetGameResult() for each game
+    in turn: 512 round trips per ply at 256 games)."""
+
+    def __init__(self, eng, res, C):
+        self.eng, self.res, self.C = eng, res, C
+        self._succ = None
+
+    def child_views(self, root):
+        g = root._g
+        n = int(self.res["n_children"][g])
+        flats, visits = self.res["flat"][g, :n].tolist(), self.res["visits"][g, :n].tolist()
+        return [_RootChild(f, v, k, root) for k, (f, v) in enumerate(zip(flats, visits))]
+
+    def _successors(self):
+        if self._succ is None:
+            import numpy as np
+            n = self.res["n_children"].astype(np.int64)
+            roots = self.res["boards"]._pods                         # the root PODs as the search left them
+            width = self.res["flat"].shape[1]
+            live = np.arange(width)[None, :] < n[:, None]
+            flats = self.res["flat"][live]                           # row-major: game by game, ascending flat index
+            pre = engine().take_action_np(np.repeat(roots, n, axis=0), flats)
+            post = pre.copy()
+            results = engine().game_result_np(post)                  # rewrites `post` in place (piece-list order)
+            offs = np.concatenate([[0], np.cumsum(n)])
+            self._succ = (offs, pre, post, results, roots)
+        return self._succ
+
+    def successor(self, g, flat, parent_pod):
+        """(successor POD, (its bytes, POD after GetGameResult, result)) of root g's child `flat`, or None when
+        `flat` is no root child or the caller's position is not the root this search was run on"""
+        import ctypes as C
+        import numpy as np
+        offs, pre, post, results, roots = self._successors()
+        n = int(self.res["n_children"][g])
+        row = self.res["flat"][g, :n]
+        k = int(np.searchsorted(row, flat))
+        if k >= n or int(row[k]) != flat or bytes(parent_pod) != roots[g].tobytes():
+            return None
+        i = int(offs[g]) + k
+        return _ffi.board_of(pre[i]), (pre[i].tobytes(), post[i], int(results[i]))
+
+
 class Board:                            # board.h:18-131, wrapper.cpp:165-226
     num_state_channels = 24
+    _gr_cache = None    # set by TakeAction from a search root: (POD bytes, POD after GetGameResult, result)
 
     def __init__(self, turn=None, location_to_piece=None, castling_rights=None, root_state=None):
         self._root_node, self._root_state, self._memory = None, root_state, []
@@ -522,6 +695,13 @@ class Board:                            # board.h:18-131, wrapper.cpp:165-226
 
     # -- GPU-backed game logic
     def GetGameResult(self, opt_player=None):
+        c = self._gr_cache
+        if c is not None:
+            self._gr_cache = None
+            if opt_player is None and bytes(self._b) == c[0]:       # still the position TakeAction produced
+                import ctypes as C
+                C.memmove(C.byref(self._b), c[1].ctypes.data, _ffi.BOARD_BYTES)   # the call permutes the piece lists
+                return GameResult(c[2])
         pl = None if opt_player is None else [int(opt_player.GetColor())]
         return GameResult(engine().game_result([self._b], pl)[0])
 
@@ -533,14 +713,22 @@ class Board:                            # board.h:18-131, wrapper.cpp:165-226
         for frm, to, flat, promo, cap in engine().legal_moves([self._b])[0]:
             kinds = (PieceType.KNIGHT, PieceType.BISHOP, PieceType.ROOK, PieceType.QUEEN) if promo else (PieceType.NO_PIECE,)
             for k in kinds:             # promotions are emitted 4x (engine/board.cpp:82-88)
-                m = Move()
-                m._from, m._to = BoardLocation._from_sq(frm), BoardLocation._from_sq(to)
+                m = Move.__new__(Move)
+                m._ft = (BoardLocation._from_sq(frm), BoardLocation._from_sq(to))
                 m._capture, m._promo = Piece._from_byte(cap), k
                 out.append(m)
         return out
 
     def TakeAction(self, move):         # board.cpp:234-239: copy, then MakeMove with (from,to) only
-        pod = engine().take_action([self._b], [move.GetFlatIndex()])[0]
+        flat = move.GetFlatIndex()
+        rn = self._root_node
+        if rn is not None and rn._batch is not None:
+            hit = rn._batch.successor(rn._g, flat, self._b)      # prefetched with every other root child of that search
+            if hit is not None:
+                nb = Board._wrap(hit[0], like=self)
+                nb._gr_cache = hit[1]
+                return nb
+        pod = engine().take_action([self._b], [flat])[0]
         return Board._wrap(pod, like=self)
 
     def GetSimpleState(self):

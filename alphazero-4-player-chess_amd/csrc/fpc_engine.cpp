@@ -70,8 +70,9 @@ struct fpc_engine {
   void *comm = nullptr;             // ncclComm_t
   int comm_rank = 0, comm_world = 1;
   fpc_tuple *d_gather = nullptr;    // [world][gather_stride]
-  long long *d_gcounts = nullptr;   // [world + 1]: all-gathered counts; slot [world] = this rank's send value
-  int gather_stride = 0, gather_cap = 0;
+  long long *d_gcounts = nullptr;   // [2 * (world + 1)]: all-gathered (count, capacity) pairs; the last pair = this rank's send values
+  int gather_stride = 0;
+  size_t gather_cap = 0;            // tuples the receive buffer holds (world x padded count)
   std::vector<int> gather_counts;
   // ---- stats
   bool timing = false;
@@ -776,13 +777,21 @@ extern "C++" Rccl &rccl() {
   // (PyTorch-ROCm ships its own librccl.so next to its libamdhip64.so)
   if (const char *env = getenv("FPC_RCCL_LIB")) {
     r.h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
-    if (!r.h) { r.err = std::string("FPC_RCCL_LIB=") + env + " cannot be loaded: " + (dlerror() ? dlerror() : ""); return r; }   // an explicit choice: no silent substitute
+    if (!r.h) {                                   // an explicit choice: no silent substitute
+      const char *de = dlerror();                 // (dlerror() clears the message when read: once per site)
+      r.err = std::string("FPC_RCCL_LIB=") + env + " cannot be loaded: " + (de ? de : "");
+      return r;
+    }
   }
   const char *names[] = {"librccl.so", "librccl.so.1"};
   for (const char *n : names) if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
   for (const char *n : names) if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
   if (!r.h) r.h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!r.h) { r.err = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return r; }
+  if (!r.h) {
+    const char *de = dlerror();
+    r.err = std::string("librccl.so not found: ") + (de ? de : "");
+    return r;
+  }
   r.get_id = (Rccl::get_id_t)dlsym(r.h, "ncclGetUniqueId");
   r.init_rank = dlsym(r.h, "ncclCommInitRank");
   r.allgather = (Rccl::allgather_t)dlsym(r.h, "ncclAllGather");
@@ -835,7 +844,7 @@ int fpc_comm_init(fpc_engine *e, const void *id128, int rank, int world) {
   if (rc) { e->comm = nullptr; return comm_fail(e, "ncclCommInitRank", rc); }
   e->comm_rank = rank; e->comm_world = world;
   int rr;
-  if ((rr = dalloc(e, &e->d_gcounts, (size_t)world + 1))) return rr;
+  if ((rr = dalloc(e, &e->d_gcounts, 2 * ((size_t)world + 1)))) return rr;
   e->gather_counts.assign(world, 0);
   return 0;
 #endif
@@ -862,34 +871,63 @@ int fpc_allgather_tuples(fpc_engine *e, int *counts_out, int *total_out) {
   USE_DEV(e);
   Rccl &r = rccl();
   const int W = e->comm_world;
-  // 1. counts: every rank contributes one int64
-  long long mine = e->tuple_count;
-  HIPCHK(e, hipMemcpyAsync(e->d_gcounts + W, &mine, sizeof(mine), hipMemcpyHostToDevice, e->stream));
-  int rc = r.allgather(e->d_gcounts + W, e->d_gcounts, 1, /*ncclInt64*/ 4, e->comm, e->stream);
+  // 1. counts: every rank contributes two int64: its tuple count, and the padded count its buffers already hold
+  //    (send side: tuple_cap; receive side: gather_cap / world) -- so every rank can tell whether ANY rank has to
+  //    grow a buffer for this exchange, i.e. whether the agreement round of step 1b is needed at all
+  long long mine[2] = {e->tuple_count, std::min<long long>(e->tuple_cap, (long long)(e->gather_cap / (size_t)W))};
+  HIPCHK(e, hipMemcpyAsync(e->d_gcounts + 2 * W, mine, sizeof(mine), hipMemcpyHostToDevice, e->stream));
+  int rc = r.allgather(e->d_gcounts + 2 * W, e->d_gcounts, 2, /*ncclInt64*/ 4, e->comm, e->stream);
   if (rc) return comm_fail(e, "ncclAllGather(counts)", rc);
-  std::vector<long long> cnt(W);
-  HIPCHK(e, hipMemcpyAsync(cnt.data(), e->d_gcounts, (size_t)W * sizeof(long long), hipMemcpyDeviceToHost, e->stream));
+  std::vector<long long> cnt2(2 * (size_t)W), cnt(W);
+  HIPCHK(e, hipMemcpyAsync(cnt2.data(), e->d_gcounts, cnt2.size() * sizeof(long long), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  for (int i = 0; i < W; ++i) cnt[i] = cnt2[2 * (size_t)i];
   long long mx = 1;
   for (int i = 0; i < W; ++i) mx = std::max(mx, cnt[i]);
+  // 1b. room for the padded payload on both sides.  A rank that cannot make it must not simply return: the others
+  //     would block in the payload collective forever.  So nobody returns here; every rank reports a status word,
+  //     the words are all-gathered, and either all ranks go on or all of them leave with FPC_ECOMM / FPC_ENOMEM.
+  int local_rc = 0;
   if (mx > e->tuple_cap) {     // the send buffer must hold the padded count: every rank knows mx, so each grows its own
-    fpc_tuple *bigger = nullptr;   // buffer here and all of them still enter the payload collective together
-    int rr;
-    if ((rr = dalloc(e, &bigger, (size_t)mx))) return rr;
-    if (e->tuple_count) HIPCHK(e, hipMemcpyAsync(bigger, e->d_tuples, (size_t)e->tuple_count * sizeof(fpc_tuple), hipMemcpyDeviceToDevice, e->stream));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    if (e->d_tuples) { (void)hipFree(e->d_tuples); e->allocs.erase(std::find(e->allocs.begin(), e->allocs.end(), (void *)e->d_tuples)); }
-    e->d_tuples = bigger;
-    e->tuple_cap = (int)mx;
+    fpc_tuple *bigger = nullptr;
+    if ((local_rc = dalloc(e, &bigger, (size_t)mx)) == 0) {
+      hipError_t he = hipSuccess;
+      if (e->tuple_count) he = hipMemcpyAsync(bigger, e->d_tuples, (size_t)e->tuple_count * sizeof(fpc_tuple), hipMemcpyDeviceToDevice, e->stream);
+      if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+      if (he != hipSuccess) {
+        local_rc = fail(e, FPC_ENODEVICE, "growing the tuple send buffer failed: %s", hipGetErrorString(he));
+        (void)hipFree(bigger);
+        e->allocs.erase(std::find(e->allocs.begin(), e->allocs.end(), (void *)bigger));
+      } else {
+        if (e->d_tuples) { (void)hipFree(e->d_tuples); e->allocs.erase(std::find(e->allocs.begin(), e->allocs.end(), (void *)e->d_tuples)); }
+        e->d_tuples = bigger;
+        e->tuple_cap = (int)mx;
+      }
+    }
   }
-  // 2. payload, padded to the largest count: ONE collective per episode (latency-bound, SURVEY 8e)
-  if ((long long)W * mx > e->gather_cap) {
+  const size_t want = (size_t)W * (size_t)mx;           // tuples in the receive buffer (size_t: world x capacity can pass 2^31)
+  if (local_rc == 0 && want > e->gather_cap) {
     if (e->d_gather) { (void)hipFree(e->d_gather); e->allocs.erase(std::find(e->allocs.begin(), e->allocs.end(), (void *)e->d_gather)); e->d_gather = nullptr; }
     e->gather_cap = 0;
-    int rr;
-    if ((rr = dalloc(e, &e->d_gather, (size_t)W * mx))) return rr;
-    e->gather_cap = (int)(W * mx);
+    if ((local_rc = dalloc(e, &e->d_gather, want)) == 0) e->gather_cap = want;
   }
+  bool anyone_grows = false;
+  for (int i = 0; i < W; ++i) anyone_grows |= cnt2[2 * (size_t)i + 1] < mx;
+  if (anyone_grows) {
+    const std::string keep = e->err;                     // the local failure text, if any, survives the agreement round
+    long long st = local_rc == 0 ? 1 : 0;
+    std::vector<long long> sts(W, 0);
+    hipError_t he = hipMemcpyAsync(e->d_gcounts + 2 * W, &st, sizeof(st), hipMemcpyHostToDevice, e->stream);
+    if (he != hipSuccess) return fail(e, FPC_ENODEVICE, "status upload failed: %s", hipGetErrorString(he));
+    rc = r.allgather(e->d_gcounts + 2 * W, e->d_gcounts, 1, /*ncclInt64*/ 4, e->comm, e->stream);
+    if (rc) return comm_fail(e, "ncclAllGather(status)", rc);
+    HIPCHK(e, hipMemcpyAsync(sts.data(), e->d_gcounts, (size_t)W * sizeof(long long), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (local_rc) { e->err = keep; return local_rc; }
+    for (int i = 0; i < W; ++i)
+      if (!sts[i]) return fail(e, FPC_ECOMM, "rank %d could not make room for the padded tuple payload; no rank entered the payload collective", i);
+  }
+  // 2. payload, padded to the largest count: ONE collective per episode (latency-bound, SURVEY 8e)
   e->gather_stride = (int)mx;
   rc = r.allgather(e->d_tuples, e->d_gather, (size_t)mx * sizeof(fpc_tuple), /*ncclUint8*/ 1, e->comm, e->stream);
   if (rc) return comm_fail(e, "ncclAllGather(tuples)", rc);
@@ -975,7 +1013,7 @@ const char *fpc_nn_kernel(fpc_engine *e) {
   return "";
 #else
   if (!e || !e->nn.loaded) return "";
-  return e->nn.use_tower ? "k_tower" : e->nn.use_tower256 ? "k_tower256" : "k_conv3x3";
+  return e->nn.use_tower ? "k_tower" : e->nn.use_tower256 ? (e->nn.tower256_v1 ? "k_tower256" : "k_tower256w") : "k_conv3x3";
 #endif
 }
 void *fpc_stream(fpc_engine *e) { return e ? (void *)e->stream : nullptr; }

@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(64) k_nchw_to_grid(const float *x, int n, int 
 
 // ------------------------------------------------------------------------------------------------
 // weight blob (written by alphazero-4-player-chess_amd/weights.py):
-//   header  : char magic[4]="FPCW"; int32 version=2, R, F, nblocks, dtype, A_ch, Np, Kp; pad to 64 B
+//   header  : char magic[4]="FPCW"; int32 version (2: fc_layout 0 only; 3: fc_layout valid), R, F, nblocks, dtype, A_ch, Np, Kp, fc_layout; pad to 64 B
 //   sections, each 64-B aligned, in this order:
 //     stem   w16[9][Fp][32]     b f32[Fp]          (Fp = F rounded up to 128)
 //     block i: c1 w16[9][Fp][F] b f32[Fp] ; c2 w16[9][Fp][F] b f32[Fp]
@@ -440,7 +440,8 @@ struct NN {
   float *towerB = nullptr;           // [2*nblocks + 2][256] (128 used)
   bool use_tower = false;            // hidden == 128: k_tower
   int tower_waves = getenv("FPC_TOWER_WAVES") ? atoi(getenv("FPC_TOWER_WAVES")) : 8;   // developer knob (A/B): 4 = one wave per SIMD
-  bool use_tower256 = false;         // hidden == 256 on the 14x14 board: k_tower256
+  bool use_tower256 = false;         // hidden == 256: k_tower256w (any board size)
+  bool tower256_v1 = false;          // ... or, FPC_TOWER256_V1=1 on the 14x14 board, round 2's k_tower256
   void (*mark_fn)(void *, int) = nullptr;   // stage-timing hook of the engine (tag 2 = policy Linear starts)
   void *mark_ctx = nullptr;
   float vb = 0.f;
@@ -516,7 +517,8 @@ struct NN {
     if (nbytes < sizeof(BlobHeader)) { *err = "weight blob too small"; return FPC_EWEIGHTS; }
     BlobHeader h;
     memcpy(&h, blob, sizeof(h));
-    if (memcmp(h.magic, "FPCW", 4) || h.version != 2) { *err = "bad weight blob magic/version"; return FPC_EWEIGHTS; }
+    if (memcmp(h.magic, "FPCW", 4) || (h.version != 2 && h.version != 3)) { *err = "bad weight blob magic/version (this engine reads versions 2 and 3)"; return FPC_EWEIGHTS; }
+    if (h.version == 2 && h.fc_layout != 0) { *err = "weight blob version 2 carries a policy-Linear layout word (version 3 does)"; return FPC_EWEIGHTS; }
     if (h.R != dc.R || h.A_ch != dc.A_ch) { *err = "weight blob is for a different board size"; return FPC_EWEIGHTS; }
     if (h.dtype != dtype) { *err = "weight blob dtype differs from engine nn_dtype"; return FPC_EWEIGHTS; }
     if (h.F % 64 || h.F < 64 || h.F > 512 || h.nblocks < 0 || h.Np % 256 || h.Kp % 512 || h.Kp < 1024 || h.Np < dc.A || h.Kp < dc.A) {
@@ -587,22 +589,31 @@ struct NN {
       use_tower = true;
     }
     use_tower256 = false;
-    if (F == 256 && dc.R == 14 && !getenv("FPC_NO_TOWER")) {
-      // k_tower256 streams one 16 KiB slab per k-step ([256 cout][32 cin], LDS-image order, fpc_tower256.h);
-      // head convolutions are zero-padded to 256 output channels
+    if (F == 256 && !getenv("FPC_NO_TOWER")) {
+      // hidden = 256: the whole tower in one launch at every board size.  k_tower256w (default) reads its weights in
+      // MFMA fragment order [layer][tap][k-step][cout tile][lane][8] (one slab = one 32-deep k-step of one tap =
+      // 16 KiB; one slab of padding behind the last layer: the prefetch runs one k-step ahead without a branch);
+      // k_tower256 (round 2's one-wave-per-SIMD form, 14x14 only, developer knob FPC_TOWER256_V1=1 for same-box A/Bs)
+      // streams the same slabs in LDS-image order.  Head convolutions are zero-padded to 256 output channels.
+      tower256_v1 = getenv("FPC_TOWER256_V1") != nullptr && atoi(getenv("FPC_TOWER256_V1")) != 0 && dc.R == 14;
       const int layers = 2 * nblocks + 2;
-      if ((rc = dmalloc(&towerW, (size_t)layers * 9 * T2_KS * T2_SLAB, err)) || (rc = dmalloc(&stemW, (size_t)9 * T2_SLAB, err)) ||
+      if ((rc = dmalloc(&towerW, ((size_t)layers * 9 * T2_KS + 1) * T2_SLAB, err)) || (rc = dmalloc(&stemW, (size_t)9 * T2_SLAB, err)) ||
           (rc = dmalloc(&towerB, (size_t)layers * 256, err))) return rc;
       auto prep = [&](const ConvW &cw, int layer) {
-        hipLaunchKernelGGL(k_tower256_prep, dim3((9 * T2_KS * 256 * 4 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)cw.w,
-                           towerW + (size_t)layer * 9 * T2_KS * T2_SLAB, 9, cw.cout_pad);
+        if (tower256_v1)
+          hipLaunchKernelGGL(k_tower256_prep, dim3((9 * T2_KS * 256 * 4 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)cw.w,
+                             towerW + (size_t)layer * 9 * T2_KS * T2_SLAB, 9, cw.cout_pad);
+        else
+          hipLaunchKernelGGL(k_tower256w_prep, dim3((9 * T2_KS * 16 * 64 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)cw.w,
+                             towerW + (size_t)layer * 9 * T2_KS * T2_SLAB, 9, cw.cout_pad);
         (void)hipMemcpyAsync(towerB + (size_t)layer * 256, cw.b, (size_t)std::min(cw.cout_pad, 256) * 4, hipMemcpyDeviceToDevice, stream);
       };
       for (int i = 0; i < nblocks; ++i) { prep(c1[i], 2 * i); prep(c2[i], 2 * i + 1); }
       prep(vconv, 2 * nblocks);
       prep(pconv, 2 * nblocks + 1);
-      hipLaunchKernelGGL(k_tower256_prep_stem, dim3((9 * 256 * 4 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)stem.w, stemW);
-      if (hipStreamSynchronize(stream) != hipSuccess) { *err = "k_tower256_prep failed"; return FPC_ENODEVICE; }
+      if (tower256_v1) hipLaunchKernelGGL(k_tower256_prep_stem, dim3((9 * 256 * 4 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)stem.w, stemW);
+      else hipLaunchKernelGGL(k_tower256w_prep_stem, dim3((9 * 16 * 64 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)stem.w, stemW);
+      if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) { *err = "k_tower256 weight preparation failed"; return FPC_ENODEVICE; }
       use_tower256 = true;
     }
     loaded = true;
@@ -678,8 +689,19 @@ struct NN {
       }
       if (use_tower256) {
         bool &a256 = attr_tower256[DT];
-        if (!a256) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower256<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS); a256 = true; }
-        hipLaunchKernelGGL((k_tower256<DT>), dim3(n), dim3(TW_THREADS), T2_LDS, stream, t);
+        if (!a256) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower256<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower256w<DT, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower256w<DT, 5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower256w<DT, 7, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower256w<DT, 7, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS);
+          a256 = true;
+        }
+        if (tower256_v1) hipLaunchKernelGGL((k_tower256<DT>), dim3(n), dim3(TW_THREADS), T2_LDS, stream, t);
+        else if (mt == 3) hipLaunchKernelGGL((k_tower256w<DT, 3, false>), dim3(n), dim3(T3_THREADS), T3_LDS, stream, t);
+        else if (mt == 5) hipLaunchKernelGGL((k_tower256w<DT, 5, false>), dim3(n), dim3(T3_THREADS), T3_LDS, stream, t);
+        else if (P != 16) hipLaunchKernelGGL((k_tower256w<DT, 7, false>), dim3(n), dim3(T3_THREADS), T3_LDS, stream, t);
+        else hipLaunchKernelGGL((k_tower256w<DT, 7, true>), dim3(n), dim3(T3_THREADS), T3_LDS, stream, t);
       } else if (mt == 3 && tower_waves == 8) hipLaunchKernelGGL((k_tower<DT, 3, false, 8>), dim3(n), dim3(512), TW_LDS, stream, t);
       else if (mt == 3) hipLaunchKernelGGL((k_tower<DT, 3, false, 4>), dim3(n), dim3(256), TW_LDS, stream, t);
       else if (mt == 5 && tower_waves == 8) hipLaunchKernelGGL((k_tower<DT, 5, false, 8>), dim3(n), dim3(512), TW_LDS, stream, t);

@@ -55,6 +55,47 @@ class Tuple(C.Structure):
 assert C.sizeof(Tuple) == 1280
 
 P = C.POINTER
+BOARD_BYTES = C.sizeof(Board)
+TURN_OFFSET = Board.turn.offset          # byte of a POD row that holds the side to move
+
+
+def _bp(pods):
+    """Board* over a C-contiguous [n, 288] uint8 array"""
+    return C.cast(pods.ctypes.data, P(Board))
+
+
+def pods_of(boards):
+    """list of Board -> [n, 288] uint8 array (copy)"""
+    out = np.zeros((len(boards), BOARD_BYTES), np.uint8)
+    for i, b in enumerate(boards):
+        C.memmove(out[i].ctypes.data, C.byref(b), BOARD_BYTES)
+    return out
+
+
+def board_of(row):
+    """one [288] uint8 row -> Board (copy)"""
+    b = Board()
+    C.memmove(C.byref(b), row.ctypes.data, BOARD_BYTES)
+    return b
+
+
+class _LazyBoards:
+    """search_results()["boards"]: Board objects made when indexed (a search returns hundreds of roots; most callers
+    read none of them as objects)"""
+
+    def __init__(self, pods):
+        self._pods = pods
+
+    def __len__(self):
+        return self._pods.shape[0]
+
+    def __getitem__(self, g):
+        return board_of(self._pods[g])
+
+    def __iter__(self):
+        return (board_of(self._pods[g]) for g in range(self._pods.shape[0]))
+
+
 _SIGS = {
     "fpc_abi_version": (C.c_int, []),
     "fpc_create": (C.c_int, [P(Config), P(C.c_void_p)]),
@@ -289,18 +330,50 @@ class Engine:
     def search_run(self, sims):
         self._chk(self.L.fpc_search_run(self.h, sims))
 
-    def search_results(self, max_children=256, roots=None):
+    def search_results(self, max_children=256, roots=None, roots_np=None):
+        """roots: list of Board to receive the root PODs as the search left them (piece-list order);
+        roots_np: the same for a [G, 288] uint8 array (no per-game Python work)"""
         G = self.G
         rv = np.zeros(G, np.int32); nc = np.zeros(G, np.int32); sd = np.zeros(G, np.int32)
         cf = np.zeros((G, max_children), np.int32); cv = np.zeros((G, max_children), np.int32)
         cp = np.zeros((G, max_children), np.float32); cw = np.zeros((G, max_children), np.float64)
-        arr = (Board * G)()
-        self._chk(self.L.fpc_search_results(self.h, arr, rv.ctypes.data, nc.ctypes.data, sd.ctypes.data, max_children,
+        pods = np.zeros((G, BOARD_BYTES), np.uint8) if roots_np is None else roots_np
+        assert pods.shape == (G, BOARD_BYTES) and pods.dtype == np.uint8 and pods.flags.c_contiguous
+        self._chk(self.L.fpc_search_results(self.h, _bp(pods), rv.ctypes.data, nc.ctypes.data, sd.ctypes.data, max_children,
                                             cf.ctypes.data, cv.ctypes.data, cp.ctypes.data, cw.ctypes.data))
         if roots is not None:
-            self._writeback(arr, roots)
+            for g, b in enumerate(roots):
+                C.memmove(C.byref(b), pods[g].ctypes.data, BOARD_BYTES)
         return {"root_n": rv, "n_children": nc, "sims_done": sd, "flat": cf, "visits": cv, "prior": cp, "w": cw,
-                "boards": [clone_board(arr[g]) for g in range(G)]}
+                "boards": _LazyBoards(pods)}
+
+    # ---- the same position ops on [n, 288] uint8 arrays of PODs (callers that keep a whole batch in one array:
+    #      bench.py's per-ply host section, mcts.py's root-children prefetch) ----
+    def search_begin_np(self, pods, c_puct):
+        assert pods.ndim == 2 and pods.shape[1] == BOARD_BYTES and pods.dtype == np.uint8 and pods.flags.c_contiguous
+        self.G = pods.shape[0]
+        self._chk(self.L.fpc_search_begin(self.h, _bp(pods), self.G, float(c_puct)))
+
+    def take_action_np(self, pods, flats):
+        """pods [n, 288] (left untouched), flats int32 [n] -> the n successor PODs"""
+        pods = np.ascontiguousarray(pods, np.uint8)
+        fl = np.ascontiguousarray(flats, np.int32)
+        n = pods.shape[0]
+        out = np.zeros((n, BOARD_BYTES), np.uint8)
+        if n:
+            self._chk(self.L.fpc_boards_take_action(self.h, _bp(pods), C.cast(fl.ctypes.data, P(C.c_int)), n, _bp(out)))
+        return out
+
+    def game_result_np(self, pods, players=None):
+        """GetGameResult of every POD of the C-contiguous array `pods`, which is rewritten in place (the reference's
+        GetGameResult permutes the piece lists); returns int32 [n]"""
+        assert pods.dtype == np.uint8 and pods.flags.c_contiguous
+        n = pods.shape[0]
+        res = np.zeros(n, np.int32)
+        pl = None if players is None else C.cast(np.ascontiguousarray(players, np.int32).ctypes.data, P(C.c_int))
+        if n:
+            self._chk(self.L.fpc_boards_game_result(self.h, _bp(pods), n, pl, C.cast(res.ctypes.data, P(C.c_int))))
+        return res
 
     def grandchildren(self, game, child_idx, max_children=256):
         n = C.c_int()
@@ -354,13 +427,23 @@ class Engine:
         self._chk(self.L.fpc_tuples_reset(self.h))
 
     def collect_tuples(self, game_ids, ply):
-        """one tuple per game of the search that just finished (root mailbox, side to move, sparse pi)"""
-        ids = (C.c_int * len(game_ids))(*game_ids) if game_ids is not None else None
+        """one tuple per game of the search that just finished (root mailbox, side to move, sparse pi);
+        game_ids: sequence or int32 array"""
+        ids = None
+        if game_ids is not None:
+            ia = np.ascontiguousarray(game_ids, np.int32)
+            ids = C.cast(ia.ctypes.data, P(C.c_int))
         self._chk(self.L.fpc_collect_tuples(self.h, ids, int(ply)))
 
     def tuples_set_z(self, game_ids, z_team0, z_team1):
-        n = len(game_ids)
-        self._chk(self.L.fpc_tuples_set_z(self.h, (C.c_int * n)(*game_ids), (C.c_float * n)(*z_team0), (C.c_float * n)(*z_team1), n))
+        """one call for any number of finished games (sequences or arrays)"""
+        ia = np.ascontiguousarray(game_ids, np.int32)
+        z0 = np.ascontiguousarray(z_team0, np.float32)
+        z1 = np.ascontiguousarray(z_team1, np.float32)
+        n = ia.shape[0]
+        assert z0.shape[0] == n and z1.shape[0] == n
+        self._chk(self.L.fpc_tuples_set_z(self.h, C.cast(ia.ctypes.data, P(C.c_int)), C.cast(z0.ctypes.data, P(C.c_float)),
+                                          C.cast(z1.ctypes.data, P(C.c_float)), n))
 
     def tuples_count(self):
         return self.L.fpc_tuples_count(self.h)

@@ -94,19 +94,16 @@ class MCTS:
         else:
             self._search_external(eng, G, sims)
         res = eng.search_results(roots=pods)          # root states keep the piece-list order the search left
+        # the roots are views of the result arrays: child objects are made when GetChildren() is first called on a
+        # root, TakeAction / GetGameResult of a root child come from one batched prefetch (alphazero_cpp._SearchBatch)
+        batch = az._SearchBatch(eng, res, self.args["C"])
         roots = []
         for g, game in enumerate(games):
             root = az.Node(self.args["C"], game, visit_count=int(res["root_n"][g]))
-            for k in range(int(res["n_children"][g])):
-                ch = az.Node(self.args["C"], None, root, az.Move(int(res["flat"][g, k])), float(res["prior"][g, k]),
-                             int(res["visits"][g, k]))
-                ch._value_sum = float(res["w"][g, k])
-                ch._lazy = (eng, g, k)
-                root._children.append(ch)
+            root._batch, root._g = batch, g
             game.SetRootNode(root)
             roots.append(root)
-        for r in roots:
-            assert len(r._children) > 0                 # mcts.py:40-41
+        assert int(res["n_children"].min()) > 0         # mcts.py:40-41
         return roots
 
     def _search_external(self, eng, G, sims):

@@ -95,7 +95,11 @@ def export_weights(model, dtype=0, fc_layout=None):
     vw[:, :24] = _cpu(vfc.weight).view(24, RR).t()
     secs.append(vw.numpy().astype(np.float32).tobytes())
     secs.append(struct.pack("<f", float(_cpu(vfc.bias).item())))
-    out = bytearray(struct.pack("<4s9i24x", b"FPCW", 2, R, F, nblocks, dtype, A_ch, Np, Kp, fc_layout))
+    # version 2: the policy Linear in k_fc's 32x32x16 fragment order (the header word that now holds fc_layout was
+    # padding then); version 3: fc_layout says which order -- an engine built before that word existed reads a
+    # layout-1 blob as layout 0, so such blobs carry a version it refuses
+    version = 2 if fc_layout == 0 else 3
+    out = bytearray(struct.pack("<4s9i24x", b"FPCW", version, R, F, nblocks, dtype, A_ch, Np, Kp, fc_layout))
     assert len(out) == 64
     for s in secs:
         out += b"\0" * ((-len(out)) % 64)

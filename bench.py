@@ -112,6 +112,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true", help="developer knob: no HIP events between the stages (what do they cost?)")
     ap.add_argument("--no-alt-policy-head", action="store_true", help="skip the extra legal-only-policy-head measurement")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the extra measurement through mcts.MCTS.search + the reference's play loop")
     ap.add_argument("--policy-head", choices=["full", "legal"], default="full",
                     help="full: whole policy Linear + full softmax (reference arithmetic, the headline); legal: opt-in legal-moves-only head")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
@@ -139,6 +140,30 @@ def workload_label(G, sims, blocks, hidden, R):
     return "custom (not a BASELINE.json config): " + shape
 
 
+def cpu_share(local_rank, local_world, cpus=None):
+    """rank r's slice of the CPUs this process may run on (contiguous, disjoint, at least one each while
+    there are at least as many CPUs as ranks; with fewer CPUs than ranks the ranks take turns on them)"""
+    cpus = sorted(os.sched_getaffinity(0)) if cpus is None else sorted(cpus)
+    n = len(cpus)
+    if n >= local_world:
+        lo, hi = local_rank * n // local_world, (local_rank + 1) * n // local_world
+        return cpus[lo:hi]
+    return [cpus[local_rank % n]]
+
+
+def pin_rank(local_rank, local_world):
+    """apply this rank's CPU share: the launcher's choice (FPC_BENCH_CPUS) or, under an external launcher such as
+    torch.distributed.run, the same slice computed from the inherited mask.  Returns the CPUs now in force."""
+    want = os.environ.get("FPC_BENCH_CPUS")
+    cpus = [int(c) for c in want.split(",") if c != ""] if want else (cpu_share(local_rank, local_world) if local_world > 1 else None)
+    if cpus:
+        try:
+            os.sched_setaffinity(0, cpus)
+        except OSError:
+            pass
+    return sorted(os.sched_getaffinity(0))
+
+
 def launch_ranks(args, argv):
     """`bench.py --gpus N` without torchrun: this process becomes the launcher.  It has made no HIP /
     torch.cuda call (torch is not even imported yet), starts one child per GPU with the torchrun
@@ -157,7 +182,10 @@ def launch_ranks(args, argv):
     for r in range(n):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "FPC_BENCH_LAUNCHER_PID": str(os.getpid())})
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "FPC_BENCH_LAUNCHER_PID": str(os.getpid()),
+                    # every rank gets its own share of the host cores this job may use (the per-ply host section and
+                    # the launch queue of one rank must not migrate onto, or share a core with, another rank's)
+                    "FPC_BENCH_CPUS": ",".join(str(c) for c in cpu_share(r, n))})
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         out = subprocess.PIPE if args.launch_dry_run else None
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out))
@@ -173,7 +201,7 @@ def launch_ranks(args, argv):
             if code != 0:
                 rc, failed = (code if code > 0 else 1), r
                 break
-        if time.time() > deadline:
+        if rc == 0 and time.time() > deadline:      # a rank's own exit code, found in this same pass, is the verdict
             rc, failed = 124, -1
         if live and rc == 0:
             time.sleep(0.05)
@@ -208,8 +236,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    cpus_in_force = pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     if args.launch_dry_run:
-        print(json.dumps({"launch_probe": {"rank": rank, "local_rank": local, "world": world,
+        print(json.dumps({"launch_probe": {"rank": rank, "local_rank": local, "world": world, "cpus": cpus_in_force,
                                            "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")),
                                            "ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}}), flush=True)
         sys.exit(int(os.environ.get("FPC_BENCH_PROBE_EXIT_RANK%d" % rank, "0")))
@@ -241,45 +270,54 @@ def main():
     eng.load_weights(weights.export_weights(model, dt))
     nn_kernel = (eng.L.fpc_nn_kernel(eng.h) or b"").decode()
     turn, entries = positions.start_entries(R)
-    start = fpc_ffi.board_from_dict(R, turn, entries)
-    boards = [fpc_ffi.clone_board(start) for _ in range(G)]
+    start = fpc_ffi.pods_of([fpc_ffi.board_from_dict(R, turn, entries)])[0]       # the start position as one 288-byte row
+    boards = np.repeat(start[None, :], G, axis=0)                                  # [G, 288]: all concurrent games in one array
     rng = np.random.default_rng(1234 + rank)
     # episode bookkeeping: every concurrent game carries a job-wide unique id (id mod world = the rank
     # that played it); tuples are built on the device by fpc_collect_tuples, z is assigned when a game
     # ends (alphazero.py:128-137, quirk Q12) or, for games still running at the end, by the material
     # heuristic (alphazero.py:161-175)
-    state = {"ids": [g * world + rank for g in range(G)], "next": G, "ply": [0] * G, "step": 0}
+    state = {"ids": (np.arange(G, dtype=np.int64) * world + rank).astype(np.int32), "next": G, "ply": np.zeros(G, np.int64), "step": 0,
+             "host_s": 0.0, "enqueue_s": 0.0, "plies": 0}
     eng.tuples_reserve(G * (args.steps + 1))
+    TURN = fpc_ffi.TURN_OFFSET
 
     def step(record):
+        """one ply of every game.  The host section behind the search (move choice, tuples, TakeAction,
+        GetGameResult, episode bookkeeping: alphazero.py:104-144) works on whole arrays: no per-game Python."""
         nonlocal boards
-        eng.search_begin(boards, 3.0)
+        t_a = time.perf_counter()
+        eng.search_begin_np(boards, 3.0)
         eng.search_run(sims)
-        res = eng.search_results(roots=boards)
+        t_b = time.perf_counter()                       # every launch of the ply is queued; the GPU is at work
+        res = eng.search_results(roots_np=boards)       # blocks until the search is done; roots come back as the search left them
+        t_c = time.perf_counter()
         flats = pick_moves(res, rng, 1.1)
         if record:      # (state, pi) of this ply for every game, on the device
             eng.collect_tuples(state["ids"], state["step"])
         state["step"] += 1
-        ok = [g for g in range(G) if flats[g] >= 0]
-        nxt = eng.take_action([boards[g] for g in ok], [int(flats[g]) for g in ok])
-        results = eng.game_result(nxt)
-        done_ids, z0, z1 = [], [], []
-        for g, nb, r in zip(ok, nxt, results):
-            state["ply"][g] += 1
-            if r == 0:
-                boards[g] = nb
-                continue
-            losing_team = boards[g].turn & 1               # the team that just moved (Q12)
-            done_ids.append(state["ids"][g]); z0.append(1.0 if losing_team != 0 else -1.0); z1.append(1.0 if losing_team != 1 else -1.0)
-            boards[g] = fpc_ffi.clone_board(start)         # finished game -> new episode, new id
-            state["ids"][g] = state["next"] * world + rank
-            state["next"] += 1
-            state["ply"][g] = 0
-        for g in range(G):
-            if flats[g] < 0:
-                boards[g] = fpc_ffi.clone_board(start)
-        if record and done_ids:
-            eng.tuples_set_z(done_ids, z0, z1)
+        ok = np.nonzero(flats >= 0)[0]
+        nxt = eng.take_action_np(boards[ok], flats[ok])
+        results = eng.game_result_np(nxt)               # rewrites nxt in place like the reference's GetGameResult (list order)
+        state["ply"][ok] += 1
+        cont = results == 0
+        done = ok[~cont]
+        losing_team = boards[done, TURN] & 1            # the team that just moved (Q12): the turn BEFORE the move
+        done_ids = state["ids"][done].copy()
+        z0 = np.where(losing_team != 0, 1.0, -1.0).astype(np.float32)
+        z1 = np.where(losing_team != 1, 1.0, -1.0).astype(np.float32)
+        boards[ok[cont]] = nxt[cont]
+        fresh = np.concatenate([done, np.nonzero(flats < 0)[0]])
+        boards[fresh] = start                           # finished game -> new episode ...
+        state["ids"][done] = ((state["next"] + np.arange(len(done))) * world + rank).astype(np.int32)   # ... under a new id
+        state["next"] += len(done)
+        state["ply"][done] = 0
+        if record and len(done):
+            eng.tuples_set_z(done_ids, z0, z1)          # all games that ended on this ply in one call
+        t_d = time.perf_counter()
+        state["host_s"] += t_d - t_c
+        state["enqueue_s"] += t_b - t_a
+        state["plies"] += 1
         return int(res["sims_done"].sum())
 
     def sync():
@@ -302,11 +340,9 @@ def main():
         """episode end: z of the games still running (heuristic), then the all-gather of this rank's
         tuples over RCCL/xGMI, issued by the engine's C++ host.  Only the collective runs
         here (inside the timed region); the records are parsed afterwards, at every N alike."""
-        ids, z0, z1 = [], [], []
-        for g in range(G):
-            h = eng.L.fpc_board_heuristic(boards[g], boards[g].turn & 1) * 0.02
-            ids.append(state["ids"][g]); z0.append(h if (boards[g].turn & 1) == 0 else -h); z1.append(h if (boards[g].turn & 1) == 1 else -h)
-        eng.tuples_set_z(ids, z0, z1)
+        team = (boards[:, TURN] & 1).astype(np.int64)
+        h = np.array([eng.L.fpc_board_heuristic(fpc_ffi.board_of(boards[g]), int(team[g])) for g in range(G)], np.float64) * 0.02
+        eng.tuples_set_z(state["ids"], np.where(team == 0, h, -h), np.where(team == 1, h, -h))
         return tuples_mod.exchange_raw(eng)
 
     exchange = {"path": "single process (no exchange)", "backend": None}
@@ -325,6 +361,7 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    state.update({"host_s": 0.0, "enqueue_s": 0.0, "plies": 0})
     eng.stats_reset()
     eng.set_timing(not args.no_stage_timing)
     sync()
@@ -337,6 +374,8 @@ def main():
     t1 = time.perf_counter()
     eng.set_timing(False)
     elapsed = t1 - t0
+    host_ms_per_ply = 1e3 * state["host_s"] / max(state["plies"], 1)
+    enqueue_ms_per_ply = 1e3 * state["enqueue_s"] / max(state["plies"], 1)
     st = eng.stats()
     elapsed, total = reduce_pair(elapsed, total)
     # outside the timed region: what arrived?  ranks_seen = distinct source ranks among the gathered game ids
@@ -381,8 +420,8 @@ def main():
         eng.set_policy_mode(args.policy_head == "legal")
         eng.load_weights(weights.export_weights(model, odt))
         eng.tuples_reserve(G)
-        boards = [fpc_ffi.clone_board(start) for _ in range(G)]
-        state.update({"ids": [g * world + rank for g in range(G)], "next": G, "ply": [0] * G, "step": 0})
+        boards = np.repeat(start[None, :], G, axis=0)
+        state.update({"ids": (np.arange(G, dtype=np.int64) * world + rank).astype(np.int32), "next": G, "ply": np.zeros(G, np.int64), "step": 0})
         step(False)
         sync()
         b0 = time.perf_counter()
@@ -446,6 +485,7 @@ def main():
         # dominant kernel: the residual tower (stem + 2*Nb residual convs + both head convs), one launch per network forward
         "roofline": {"bound": "mfma", "achieved": ach_tower, "peak": peak, "unit": "TFLOP/s", "frac": ach_tower / peak,
                      "traffic": pmc_traffic([nn_kernel], shape_key),
+                     "traffic_source": "profiles/pmc_summary.json[%s] (rocprofv3 --pmc passes of an earlier run of this kernel and shape, committed; NOT counted in this run)" % shape_key,
                      "kernel": tower_desc,
                      "flops_per_launch": flops_tower, "ms_per_launch": tower_ms},
         # the policy Linear at M = 256: 255 FLOP per weight byte, below the 312 FLOP/B ridge -> HBM-bound.
@@ -453,11 +493,21 @@ def main():
         "roofline_policy_linear": {"bound": "hbm", "achieved": fc_bytes / (fc_ms * 1e-3) / 1e9 if fc_ms > 0 else 0.0, "peak": PEAK_HBM_GBS,
                                    "unit": "GB/s", "frac": (fc_bytes / (fc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if fc_ms > 0 else 0.0,
                                    "traffic": pmc_traffic(fc_kernels, shape_key),
+                                   "traffic_source": "profiles/pmc_summary.json[%s] (committed PMC passes, not counted in this run)" % shape_key,
                                    "kernel": " + ".join(fc_kernels) + " (weight-streaming Linear, %.2f GB of 16-bit weights per launch)" % (2.0 * Np * Kp / 1e9),
                                    "bytes_per_launch": fc_bytes, "flops_per_launch": flops_fc, "ms_per_launch": fc_ms,
                                    "mfma_TFLOPs": ach_fc},
         "stage_ms_per_sim_step": {"select+encode": sel_ms, "tower": tower_ms, "policy_linear": fc_ms, "expand+backup": exp_ms},
-        "stage_note": "expand+backup is k_expand_select = expansion + backup of step s and selection of step s+1; select+encode is what is left between two steps (event overhead) plus the first step's k_select",
+        "stage_note": "HIP-event intervals on the engine's stream, sampled on every 16th simulation step and scaled: they include the "
+                      "launch boundary behind each kernel and read 2-3 % above the kernel-trace durations (profiles/r03: 0.2574 ms "
+                      "here vs 0.2554 ms traced for k_tower), so the four do not add up to ms_per_step / sims exactly; expand+backup is "
+                      "k_expand_select = expansion + backup of step s and selection of step s+1; select+encode is what is left between "
+                      "two steps plus the first step's k_select",
+        # host side of one ply (one `step`): what runs between search_results returning and the next search_begin
+        # (move choice, tuples, TakeAction, GetGameResult, episode bookkeeping; all array-wide), and the time the
+        # launches of a ply take to queue (overlapped with the GPU).  At N ranks on one host these show contention.
+        "host_ms_per_ply": host_ms_per_ply, "enqueue_ms_per_ply": enqueue_ms_per_ply,
+        "host_cpus": {"count": len(cpus_in_force), "first": cpus_in_force[0], "last": cpus_in_force[-1]},
         "tree_hbm": {"bound": "hbm", "algorithmic_bytes_per_sim": tree_bytes_per_sim(R),
                      "achieved": tree_bytes_per_sim(R) * G / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0,
                      "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -473,11 +523,93 @@ def main():
         out["alt_dtype_" + other] = alt_dtype
     if world == 1 and not args.no_alt_dtype:
         out["float_parity"] = float_parity(R, args.blocks, args.hidden, INV)
+    if world == 1 and not args.no_dropin:
+        # the same workload through the reference's own entry point (drop-in surface), beside the headline
+        out["dropin"] = dropin_measure(model, R, G, sims, dt)
+        out["dropin_sims_per_s"] = out["dropin"]["value"]
+        out["dropin_over_value"] = out["dropin"]["value"] / out["value"]
     out["config"]["policy_head"] = args.policy_head
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def dropin_measure(model, R, G, sims, dt, plies=3):
+    """The same workload through the DROP-IN surface instead of the C-ABI: `mcts.MCTS(gameType, model, args).search(states)`
+    followed, per game, by exactly the calls of the reference's play loop (alphazero.py:99-144): GetChildren /
+    GetMoveMade().GetFlatIndex() / GetVisitCount into pi, MemoryEntry, the temperature draw, Move(flat), TakeAction,
+    SetRootState(GetRootState()), GetGameResult, finished games deleted from the list -- one game at a time, in Python,
+    as the reference does it.  The caller's own arithmetic (pi / pow / the draw) is done on the children's entries only:
+    the same numbers as the reference's dense 23 520-wide torch ops, which belong to the caller, not to the surface
+    measured here.  One untimed ply, then `plies` timed ones; sims/s counts the simulations the searches really made."""
+    import alphazero_cpp as az
+    az.configure(R)
+    from fen_parser import parse_board_args_from_fen
+    from four_player_chess_board import FourPlayerChess
+    from mcts import MCTS
+    import torch
+    mcts = MCTS(FourPlayerChess, model, {"C": 3.0, "num_searches": sims, "nn_dtype": dt, "pool_size": 10})
+    rng = np.random.default_rng(99)
+    states = [FourPlayerChess(*parse_board_args_from_fen(FourPlayerChess.start_fen, R)) for _ in range(G)]
+    T = 1.1
+    clk = time.perf_counter
+    sims_done, t0 = 0, None
+    sec = {"search": 0.0, "children_reads": 0.0, "caller_arithmetic": 0.0, "take_action_game_result": 0.0, "other_surface_calls": 0.0}
+    for ply in range(plies + 1):
+        if ply == 1:
+            torch.cuda.synchronize()
+            sims_done, t0 = 0, clk()
+            for k in sec:
+                sec[k] = 0.0
+        ta = clk()
+        roots = mcts.search(states)
+        sec["search"] += clk() - ta
+        for i in reversed(range(len(states))):
+            state = states[i]
+            t1 = clk()
+            flats, visits = [], []
+            for child in roots[i].GetChildren():
+                flats.append(child.GetMoveMade().GetFlatIndex())
+                visits.append(child.GetVisitCount())
+            sims_done += int(roots[i].GetVisitCount()) - 1             # root N = 1 + simulations made (mcts.py:30)
+            t2 = clk()
+            pi = np.asarray(visits, np.float32)
+            pi /= pi.sum()
+            tp = np.power(pi, np.float32(1.0 / T))
+            c = np.cumsum(tp.astype(np.float64))
+            action_index = flats[min(int(np.searchsorted(c, rng.random() * c[-1], side="right")), len(flats) - 1)]
+            t3 = clk()
+            state.AppendToMemory(az.MemoryEntry(state, (flats, pi)))
+            action = az.Move(action_index)
+            t4 = clk()
+            next_state = state.TakeAction(action)
+            t5 = clk()
+            next_state.SetRootState(state.GetRootState())
+            t6 = clk()
+            game_state = next_state.GetGameResult()
+            t7 = clk()
+            if game_state != az.GameResult.IN_PROGRESS:
+                del states[i]
+            else:
+                states[i] = next_state
+            sec["children_reads"] += t2 - t1
+            sec["caller_arithmetic"] += t3 - t2
+            sec["other_surface_calls"] += (t4 - t3) + (t6 - t5)
+            sec["take_action_game_result"] += (t5 - t4) + (t7 - t6)
+        while len(states) < G:        # keep the batch at G games (the reference lets it shrink; throughput is quoted at G)
+            states.append(FourPlayerChess(*parse_board_args_from_fen(FourPlayerChess.start_fen, R)))
+    dt_s = clk() - t0
+    eng = az.engine()
+    eng.close()
+    az._engine = None
+    return {"value": sims_done / dt_s, "unit": "sims/s", "plies": plies, "ms_per_ply": 1e3 * dt_s / plies,
+            "ms_per_ply_by_part": {k: 1e3 * v / plies for k, v in sec.items()},
+            "parts": "search = MCTS.search (weights check, upload of the roots, the whole search on the GPU, root read-back); children_reads = "
+                     "GetChildren + GetMoveMade().GetFlatIndex() + GetVisitCount for every root child; take_action_game_result = TakeAction + "
+                     "GetGameResult per game (answered from ONE batched prefetch per search); other_surface_calls = MemoryEntry, Move(flat), "
+                     "GetRootState / SetRootState; caller_arithmetic = pi, temperature, the draw (the caller's, on the children's entries)",
+            "path": "mcts.MCTS.search + the reference's play loop (alphazero.py:99-144), one game at a time in Python"}
 
 
 def float_parity(R, blocks, hidden, INV):

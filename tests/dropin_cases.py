@@ -217,3 +217,62 @@ def case_host_tree(backend, R, max_cases=3, max_sims=100, use_reference_mcts=Fal
         assert state_pl == ref["after"]
         done += 1
     return done
+
+
+def case_play_loop_prefetch(backend, R, games=6, plies=4, sims=24):
+    """alphazero.py:99-144 written the way the reference writes it -- per game: GetChildren / GetMoveMade().GetFlatIndex()
+    / GetVisitCount, MemoryEntry, TakeAction(Move(flat)), SetRootState, GetGameResult -- over MCTS.search.  The shim
+    answers TakeAction / GetGameResult of a searched root from ONE batched prefetch per search
+    (alphazero_cpp._SearchBatch); every successor position (bytes, i.e. incl. piece-list order, before and after
+    GetGameResult) and every result must equal what the engine returns for the same calls made one by one."""
+    az = setup(backend, R)
+    import ctypes as C
+    from fen_parser import parse_board_args_from_fen
+    from four_player_chess_board import FourPlayerChess
+    from mcts import MCTS
+    mcts = MCTS(FourPlayerChess, Eval("hash", R), {"C": 3.0, "num_searches": sims, "pool_size": 10})
+    states = [FourPlayerChess(*parse_board_args_from_fen(FourPlayerChess.start_fen, R)) for _ in range(games)]
+    rng = np.random.default_rng(7)
+    checked = 0
+    for ply in range(plies):
+        roots = mcts.search(states)
+        eng = az.engine()
+        for i in reversed(range(len(states))):
+            state = states[i]
+            probs = np.zeros(FourPlayerChess.action_space_size)
+            kids = roots[i].GetChildren()
+            assert kids and all(isinstance(c, az.Node) and isinstance(c.GetMoveMade(), az.Move) for c in kids)
+            for child in kids:
+                probs[child.GetMoveMade().GetFlatIndex()] = child.GetVisitCount()
+            f, v = roots[i].child_arrays()
+            assert [int(x) for x in f] == [c.GetMoveMade().GetFlatIndex() for c in kids] and [int(x) for x in v] == [c.GetVisitCount() for c in kids]
+            assert kids[0].GetMoveMade().From().Present() and az.Move(kids[0].GetMoveMade()).GetFlatIndex() == kids[0].GetMoveMade().GetFlatIndex()
+            state.AppendToMemory(az.MemoryEntry(state, probs / probs.sum()))
+            pick = int(rng.choice(np.nonzero(probs)[0]))
+            # the same two calls made directly on the engine, one board at a time
+            want_pre = eng.take_action([fpc_ffi.clone_board(state._b)], [pick])[0]
+            want_post = fpc_ffi.clone_board(want_pre)
+            want_res = eng.game_result([want_post])[0]
+            nxt = state.TakeAction(az.Move(pick))
+            assert nxt._gr_cache is not None, "a root child's successor must come from the prefetch"
+            assert bytes(nxt._b) == bytes(want_pre)
+            nxt.SetRootState(state.GetRootState())
+            res = nxt.GetGameResult()
+            assert int(res) == want_res and bytes(nxt._b) == bytes(want_post)
+            assert nxt._gr_cache is None and int(nxt.GetGameResult()) == eng.game_result([fpc_ffi.clone_board(want_post)])[0]
+            checked += 1
+            if res != az.GameResult.IN_PROGRESS:
+                del states[i]
+            else:
+                states[i] = nxt
+        if not states:
+            break
+    # a position that is not the searched root falls back to the direct path
+    if states:
+        roots = mcts.search(states[:1])
+        moved = states[0].TakeAction(az.Move(int(roots[0].child_arrays()[0][0])))
+        moved.SetRootNode(roots[0])                      # wrong on purpose: not the root's position
+        lm = moved.GetLegalMoves()
+        other = moved.TakeAction(lm[0])
+        assert other._gr_cache is None
+    return checked

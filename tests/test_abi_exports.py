@@ -61,3 +61,25 @@ def test_a_library_built_from_other_sources_is_refused(tmp_path, monkeypatch):
     monkeypatch.setattr(fpc_ffi, "LIB_PATH", str(fake))
     with pytest.raises(RuntimeError, match="stale HIP engine library"):
         fpc_ffi._check_fresh()
+
+
+def test_an_unloadable_rccl_library_is_an_error_message_not_a_crash():
+    """FPC_RCCL_LIB naming a file that cannot be loaded must come back from fpc_comm_available() -- the
+    probe tuples.init_comm runs on every rank before anybody enters ncclCommInitRank -- as FPC_ECOMM with a text
+    (no silent substitute, and no segfault on the way: dlerror() reads as NULL the second time)."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys\n"
+            "L = C.CDLL(%r)\n"
+            "L.fpc_comm_available.restype = C.c_int\n"
+            "L.fpc_last_error.restype = C.c_char_p; L.fpc_last_error.argtypes = [C.c_void_p]\n"
+            "rc = L.fpc_comm_available()\n"
+            "msg = (L.fpc_last_error(None) or b'').decode()\n"
+            "print(rc, '|', msg)\n"
+            "rc2 = L.fpc_comm_available()\n"           # the verdict is cached: same answer, still no crash
+            "sys.exit(0 if (rc == rc2 and rc < 0) else 3)\n" % fpc_ffi.LIB_PATH)
+    env = dict(os.environ, FPC_RCCL_LIB="/nonexistent/librccl.so")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    assert "FPC_RCCL_LIB=/nonexistent/librccl.so cannot be loaded" in p.stdout
+    assert "cannot open shared object file" in p.stdout or "No such file" in p.stdout

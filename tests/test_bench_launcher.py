@@ -28,6 +28,37 @@ def test_launcher_starts_n_ranks_with_the_torchrun_environment():
     assert all(r["ipc_legacy"] == "0" for r in ranks)          # dmabuf IPC only on this pool (RCCL needs it)
 
 
+def test_every_rank_is_pinned_to_its_own_share_of_the_host_cores():
+    """8 ranks on 16 host cores must not migrate over each other: the launcher hands every rank
+    a disjoint, contiguous slice of its own affinity mask, and the rank applies it before importing torch."""
+    avail = sorted(os.sched_getaffinity(0))
+    n = min(4, len(avail))
+    rc, out, _ = _run(n)
+    assert rc == 0
+    shares = [r["cpus"] for r in out["ranks"]]
+    assert all(len(s) >= 1 for s in shares)
+    flat = [c for s in shares for c in s]
+    assert len(flat) == len(set(flat)), shares                  # disjoint
+    assert sorted(flat) == avail                                # together: exactly what the job may use
+    assert all(s == sorted(s) and s == avail[avail.index(s[0]):avail.index(s[0]) + len(s)] for s in shares)   # contiguous
+    assert max(len(s) for s in shares) - min(len(s) for s in shares) <= 1
+
+
+def test_cpu_share_with_fewer_cores_than_ranks_and_under_an_external_launcher():
+    sys.path.insert(0, REPO)
+    import bench
+    assert [bench.cpu_share(r, 8, cpus=range(16)) for r in range(8)] == [[2 * r, 2 * r + 1] for r in range(8)]
+    assert [bench.cpu_share(r, 4, cpus=[3, 5]) for r in range(4)] == [[3], [5], [3], [5]]
+    # torch.distributed.run form: no FPC_BENCH_CPUS, the rank derives the same slice from LOCAL_RANK / LOCAL_WORLD_SIZE
+    avail = sorted(os.sched_getaffinity(0))
+    if len(avail) >= 2:
+        env = {k: v for k, v in os.environ.items() if k != "FPC_BENCH_CPUS"}
+        env.update(RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+        p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-dry-run"], env=env, capture_output=True, text=True, timeout=60)
+        probe = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])["launch_probe"]
+        assert probe["cpus"] == avail[len(avail) // 2:]
+
+
 def test_a_failing_rank_stops_the_job_with_its_exit_code():
     rc, out, err = _run(2, {"FPC_BENCH_PROBE_EXIT_RANK1": "7"})
     assert rc == 7 and out["exit"] == 7 and "rank 1 failed" in err

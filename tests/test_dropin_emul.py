@@ -45,3 +45,8 @@ def test_the_reference_mcts_py_itself_runs_on_the_shim():
     if n < 0:
         pytest.skip("/root/reference is not present on this machine")
     assert n >= 1
+
+
+@pytest.mark.parametrize("R", [8, 14])
+def test_play_loop_takes_successors_from_one_batched_prefetch(R):
+    assert dc.case_play_loop_prefetch("emul", R) >= 6

@@ -10,6 +10,13 @@ def test_reference_style_usage(R):
     assert dc.case_reference_style_usage("gpu", R)
 
 
+@pytest.mark.parametrize("R", [8, 14])
+def test_play_loop_takes_successors_from_one_batched_prefetch(R):
+    """the reference's per-game play loop over MCTS.search: TakeAction / GetGameResult of the searched roots come from
+    one batched prefetch per search and equal the one-by-one engine calls byte for byte (incl. piece-list order)"""
+    assert dc.case_play_loop_prefetch("gpu", R, games=24, plies=6, sims=40) >= 24
+
+
 def test_native_resnet_search_through_mcts():
     """MCTS(gameType, ResNet, args).search: weights exported + fused on-device search."""
     import torch

@@ -68,11 +68,13 @@ def _positions(R, n):
         return out
     g = gold(R)
     out = []
-    for game in g["playouts"]:
-        for rec in game[::7]:
-            out.append(fpc_ffi.board_from_lists(R, rec["before"]["turn"], rec["before"]["pl"]))
-            if len(out) == n:
-                return out
+    for stride in (7, 3, 1):                     # a denser sweep of the recorded playouts when more positions are asked for
+        out = []
+        for game in g["playouts"]:
+            for rec in game[::stride]:
+                out.append(fpc_ffi.board_from_lists(R, rec["before"]["turn"], rec["before"]["pl"]))
+                if len(out) == n:
+                    return out
     return out
 
 
@@ -80,6 +82,9 @@ def _positions(R, n):
                                                        (14, 2, 64, 1, 1e-3), (14, 2, 64, 0, 8e-3),
                                                        (14, 3, 128, 1, 1e-3), (14, 3, 128, 0, 8e-3), (8, 3, 128, 0, 8e-3),
                                                        (8, 2, 256, 1, 1e-3), (10, 2, 128, 1, 1e-3),
+                                                       # hidden 256: k_tower256w at every row-tile variant (MT 3 / 5 / 7 generic / 7 fast)
+                                                       (8, 3, 256, 0, 8e-3), (10, 2, 256, 1, 1e-3), (11, 2, 256, 1, 1e-3), (12, 2, 256, 1, 1e-3),
+                                                       (13, 2, 256, 1, 1e-3), (14, 2, 256, 1, 1e-3), (14, 2, 256, 0, 8e-3),
                                                        # sizes without a reference layout: every k_tower row-tile variant
                                                        (9, 2, 128, 1, 1e-3), (11, 2, 128, 1, 1e-3), (12, 2, 128, 1, 1e-3), (13, 2, 128, 1, 1e-3)])
 def test_resnet_forward_vs_torch_fp32(R, blocks, hidden, dtype, tol):
@@ -136,6 +141,42 @@ def test_tower_wave_forms_give_identical_bits(R, blocks, monkeypatch):
         assert np.abs(outs[0][0]).mean() > 1e-3
 
 
+@pytest.mark.parametrize("dtype", [1, 0], ids=["fp16", "bf16"])
+def test_tower256_forms_give_identical_bits(dtype, monkeypatch):
+    """k_tower256w (round 4: two waves per SIMD, weights straight from L2 into registers, no barrier inside a layer) and
+    k_tower256 (round 2's one wave per SIMD with the 2-slab LDS ring; developer knob FPC_TOWER256_V1=1, 14x14 only) run
+    the same MFMAs on the same operands in the same order for every output element: logits and values must agree BIT FOR
+    BIT -- for network inputs given as planes and for the fused leaf encode (a short search)."""
+    import torch
+    import weights
+    R, G = 14, 48
+    m = _model(R, 3, 256, seed=6)
+    x = (torch.rand(G, 24, R, R, generator=torch.Generator().manual_seed(2)) < 0.1).float().cuda()
+    boards = _positions(R, 12)
+    outs = []
+    for v1 in ("0", "1"):
+        monkeypatch.setenv("FPC_TOWER256_V1", v1)
+        eng = make_engine("gpu", R, INV_OF[R], max_games=G, max_sims=24, nn_dtype=dtype)
+        eng.load_weights(weights.export_weights(m, dtype))
+        assert (eng.L.fpc_nn_kernel(eng.h) or b"").decode() == ("k_tower256" if v1 == "1" else "k_tower256w")
+        lg = torch.empty(G, eng.A, device="cuda")
+        va = torch.empty(G, device="cuda")
+        for _ in range(2):
+            eng.nn_forward(x.data_ptr(), G, lg.data_ptr(), va.data_ptr())
+        torch.cuda.synchronize()
+        roots = [fpc_ffi.clone_board(b) for b in boards]
+        eng.search_begin(roots, 3.0)
+        eng.search_run(24)
+        res = eng.search_results(roots=roots)
+        outs.append((lg.cpu().numpy().copy(), va.cpu().numpy().copy(), res))
+        eng.close()
+    monkeypatch.delenv("FPC_TOWER256_V1")
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.abs(outs[0][0]).mean() > 1e-3
+    for k in ("root_n", "n_children", "flat", "visits", "prior", "w"):
+        assert np.array_equal(outs[0][2][k], outs[1][2][k]), k
+
+
 @pytest.mark.parametrize("R,dtype", [(14, 1), (8, 0)])
 def test_both_policy_linear_kernels_meet_the_fp32_network(R, dtype):
     """k_fc16 (16x16x32, [k32][tile16] weight order: the default) and k_fc (32x32x16, fc_layout = 0 in the blob):
@@ -162,6 +203,92 @@ def test_both_policy_linear_kernels_meet_the_fp32_network(R, dtype):
     for o in outs:
         assert np.abs(o - ref_l.numpy()).max() < tol
     assert np.abs(outs[0] - outs[1]).max() < 2e-5      # same operands, f32 accumulation in another order
+
+
+def test_headline_shape_256_rows_every_row_vs_fp32_network():
+    """the headline shape -- 14x14, hidden 128, M = 256 rows -- held against the fp32 torch network
+    ROW BY ROW.  256 positions from the reference's recorded playouts fill every row tile of the policy Linear
+    (k_fc16's tiles 0..15 / k_fc's 0..7), plan_fc's long and short blocks at Mtot = 256 (126 MB of split-K slabs) and
+    k_fc_reduce's chunk records at that size; both weight fragment orders; logits AND values at north_star's 1e-3 for
+    every single row (the searches at this size only check properties that hold for wrong logits too)."""
+    import torch
+    import weights
+    R, dtype, n = 14, 1, 256
+    m = _model(R, 2, 128, seed=17)
+    boards = _positions(R, n)
+    assert len(boards) == n
+    ref_l = ref_v = enc = None
+    outs = []
+    for layout in (1, 0):
+        eng = make_engine("gpu", R, INV_OF[R], max_games=n, max_sims=4, nn_dtype=dtype)
+        eng.load_weights(weights.export_weights(m, dtype, fc_layout=layout))
+        if enc is None:
+            enc = np.concatenate([eng.encode([b]) for b in boards])      # per-position rotation
+            with torch.no_grad():
+                ref_l, ref_v = m(torch.from_numpy(enc))
+            ref_l, ref_v = ref_l.numpy(), ref_v.squeeze(1).numpy()
+        x = torch.from_numpy(enc).cuda()
+        lg = torch.empty(n, eng.A, device="cuda")
+        va = torch.empty(n, device="cuda")
+        torch.cuda.synchronize()
+        eng.nn_forward(x.data_ptr(), n, lg.data_ptr(), va.data_ptr())
+        torch.cuda.synchronize()
+        lg, va = lg.cpu().numpy(), va.cpu().numpy()
+        row_err = np.abs(lg - ref_l).max(axis=1)
+        val_err = np.abs(va - ref_v)
+        print("fc_layout %d: max|dlogit| %.3e (worst row %d), max|dvalue| %.3e, logit range %.3f" % (
+            layout, row_err.max(), int(row_err.argmax()), val_err.max(), np.abs(ref_l).max()))
+        assert np.isfinite(lg).all() and (row_err < 1e-3).all(), (layout, np.nonzero(row_err >= 1e-3)[0][:8], row_err.max())
+        assert (val_err < 1e-3).all(), (layout, val_err.max())
+        assert np.abs(lg).max(axis=1).min() > 1e-3               # every row really was computed
+        outs.append(lg)
+        eng.close()
+    assert np.abs(outs[0] - outs[1]).max() < 2e-5                # same operands, f32 accumulation in another order
+
+
+def test_fused_search_equals_stepwise_at_the_headline_size():
+    """fpc_search_run = the step-wise path at configs[1]'s full size -- 256 games x 400
+    simulations, ResNet(10,128) fp16, 14x14 -- extending the chain fused loop = step-wise loop = oracle (small sizes) to
+    the headline shape.  The step-wise leg drives fpc_search_select / fpc_nn_forward / fpc_search_expand_select from the
+    host with every tensor staying on the GPU (its network input comes from k_encode + k_nchw_to_grid, the fused
+    loop's from the tower's own leaf encode; its softmax records from k_softmax_partials, the fused loop's from
+    k_fc_reduce): visit counts, priors, value sums and the roots' piece-list orders must agree bit for bit."""
+    import torch
+    import weights
+    R, G, sims, dtype = 14, 256, 400, 1
+    m = _model(R, 10, 128, seed=0)
+    eng = make_engine("gpu", R, INV_OF[R], max_games=G, max_sims=sims, nn_dtype=dtype)
+    eng.load_weights(weights.export_weights(m, dtype))
+    boards = _positions(R, G)                                   # mixed turns and depths (quirk Q6 in every batch)
+    assert len(boards) == G
+    roots_a = [fpc_ffi.clone_board(b) for b in boards]
+    eng.search_begin(roots_a, 3.0)
+    eng.search_run(sims)
+    res_a = eng.search_results(roots=roots_a)
+
+    roots_b = [fpc_ffi.clone_board(b) for b in boards]
+    lg = torch.empty(G, eng.A, device="cuda")
+    va = torch.empty(G, device="cuda")
+    eng.search_begin(roots_b, 3.0)
+    n_live, enc_ptr = eng.search_select()
+    for i in range(sims):
+        last = i == sims - 1
+        if n_live == 0:
+            if not last:
+                n_live, enc_ptr = eng.search_select()
+            continue
+        eng.nn_forward(enc_ptr, G, lg.data_ptr(), va.data_ptr())     # device pointer in, device tensors out
+        if last:
+            eng.search_expand(lg.data_ptr(), va.data_ptr())
+        else:
+            n_live, enc_ptr = eng.search_expand_select(lg.data_ptr(), va.data_ptr())
+    res_b = eng.search_results(roots=roots_b)
+    for k in ("root_n", "n_children", "sims_done", "flat", "visits", "prior", "w"):
+        assert np.array_equal(res_a[k], res_b[k]), k
+    for a, b in zip(roots_a, roots_b):
+        assert bytes(a) == bytes(b)
+    assert int(res_a["sims_done"].sum()) > G * sims * 9 // 10
+    eng.close()
 
 
 def test_resnet_forward_more_than_256_rows():

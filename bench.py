@@ -99,14 +99,16 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", type=int, choices=[1, 3], default=None,
-                    help="BASELINE.json preset: 1 = configs[1] (256 games x 400 sims, ResNet(10,128), the default), "
-                         "3 = configs[3] (ResNet(20,256), 800 sims/move, fp16)")
-    ap.add_argument("--games", type=int, default=256, help="concurrent games per GPU")
+    ap.add_argument("--config", choices=["1", "3", "ref"], default=None,
+                    help="preset: 1 = BASELINE.json configs[1] (256 games x 400 sims, ResNet(10,128), the default), "
+                         "3 = configs[3] (ResNet(20,256), 800 sims/move, fp16), "
+                         "ref = the reference's own shipped default (alphazero.py:288-304: ResNet(15,256), 100 parallel games x "
+                         "50 searches on its compiled 8x8 EIGHT_SIMPLE board)")
+    ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (default 256; 100 with --config ref)")
     ap.add_argument("--sims", type=int, default=None)
     ap.add_argument("--blocks", type=int, default=None)
     ap.add_argument("--hidden", type=int, default=None)
-    ap.add_argument("--board", type=int, default=14)
+    ap.add_argument("--board", type=int, default=None, help="board size (default 14; 8 with --config ref)")
     ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"])
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the extra measurement with the other 16-bit operand type")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -122,10 +124,12 @@ def parse_args(argv=None):
                     help="N>1 without an external launcher: start the N ranks, have each report its environment and exit (no GPU, no torch)")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="seconds the self-launcher waits for its ranks")
     args = ap.parse_args(argv)
-    preset = {1: (400, 10, 128), 3: (800, 20, 256)}[args.config or 1]
+    preset = {"1": (400, 10, 128, 256, 14), "3": (800, 20, 256, 256, 14), "ref": (50, 15, 256, 100, 8)}[args.config or "1"]
     args.sims = preset[0] if args.sims is None else args.sims
     args.blocks = preset[1] if args.blocks is None else args.blocks
     args.hidden = preset[2] if args.hidden is None else args.hidden
+    args.games = preset[3] if args.games is None else args.games
+    args.board = preset[4] if args.board is None else args.board
     return args
 
 
@@ -137,6 +141,8 @@ def workload_label(G, sims, blocks, hidden, R):
         return "configs[1]: " + shape
     if (sims, blocks, hidden, R) == (800, 20, 256, 14):
         return "configs[3]: " + shape
+    if (G, sims, blocks, hidden, R) == (100, 50, 15, 256, 8):
+        return "reference default (alphazero.py:288-304; the model and sizes the reference ships with, not a BASELINE.json config): " + shape
     return "custom (not a BASELINE.json config): " + shape
 
 
@@ -468,7 +474,8 @@ def main():
 
     shape_key = "r%d_b%d_h%d_g%d" % (R, Nb, F, G)
     tower_desc = {"k_tower": "k_tower (residual tower megakernel, hidden 128, LDS-resident activations)",
-                  "k_tower256": "k_tower256 (residual tower megakernel, hidden 256, LDS-resident activations)",
+                  "k_tower256": "k_tower256 (residual tower megakernel, hidden 256, one wave per SIMD, 2-slab LDS weight ring; developer knob)",
+                  "k_tower256w": "k_tower256w (residual tower megakernel, hidden 256, two waves per SIMD, weights L2 -> registers, LDS-resident activations)",
                   "k_conv3x3": "k_conv3x3 x %d launches (per-layer implicit GEMM, activations through L2) + k_value_tail" % (2 * Nb + 3)}.get(nn_kernel, nn_kernel)
     fc_kernels = ["k_fc16" if weights.FC_LAYOUT == 1 else "k_fc", "k_fc_reduce"]   # the Linear (by the weight layout exported) and its split-K reduce
     tree_ms = sel_ms + exp_ms

@@ -34,7 +34,7 @@ REPO = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
 import gen_golden  # noqa: E402  (setup_imports: reference module path + line_profiler stub)
 
-NET_CASES = {14: [(10, 128, 0), (20, 256, 0)], 8: [(4, 64, 0), (10, 128, 0)]}
+NET_CASES = {14: [(10, 128, 0), (20, 256, 0)], 8: [(4, 64, 0), (10, 128, 0), (15, 256, 0)]}   # (15, 256): the reference's shipped model, alphazero.py:288
 N_POS = 32
 N_IDX = 1024
 

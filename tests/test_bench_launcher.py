@@ -85,8 +85,11 @@ def test_workload_labels_follow_the_arguments():
     a = bench.parse_args([])
     assert (a.sims, a.blocks, a.hidden) == (400, 10, 128)
     assert bench.workload_label(a.games, a.sims, a.blocks, a.hidden, a.board).startswith("configs[1]:")
+    r = bench.parse_args(["--config", "ref"])
+    assert (r.sims, r.blocks, r.hidden, r.games, r.board) == (50, 15, 256, 100, 8)
+    assert bench.workload_label(r.games, r.sims, r.blocks, r.hidden, r.board).startswith("reference default (alphazero.py:288-304")
     a = bench.parse_args(["--config", "3"])
-    assert (a.sims, a.blocks, a.hidden) == (800, 20, 256)
+    assert (a.sims, a.blocks, a.hidden, a.games, a.board) == (800, 20, 256, 256, 14)
     assert bench.workload_label(a.games, a.sims, a.blocks, a.hidden, a.board).startswith("configs[3]:")
     a = bench.parse_args(["--blocks", "20", "--hidden", "256", "--sims", "800"])
     assert bench.workload_label(a.games, a.sims, a.blocks, a.hidden, a.board).startswith("configs[3]:")

@@ -35,7 +35,7 @@ def test_train_batch_and_loss():
     assert nc.case_train_batch("emul") == 16
 
 
-@pytest.mark.parametrize("R,blocks,hidden", [(8, 4, 64), (8, 10, 128)])
+@pytest.mark.parametrize("R,blocks,hidden", [(8, 4, 64), (8, 10, 128), (8, 15, 256)])
 def test_module_equals_reference_net(R, blocks, hidden):
     """our net.py module, built under the fixture's seed, holds the reference net.py's weights
     (checksums) and reproduces its fp32 logits and values on the golden positions."""

@@ -1013,7 +1013,7 @@ const char *fpc_nn_kernel(fpc_engine *e) {
   return "";
 #else
   if (!e || !e->nn.loaded) return "";
-  return e->nn.use_tower ? "k_tower" : e->nn.use_tower256 ? (e->nn.tower256_v1 ? "k_tower256" : "k_tower256w") : "k_conv3x3";
+  return e->nn.use_towerw ? "k_towerw" : e->nn.use_tower ? "k_tower" : e->nn.tower256_v1 ? "k_tower256" : "k_conv3x3";
 #endif
 }
 void *fpc_stream(fpc_engine *e) { return e ? (void *)e->stream : nullptr; }

@@ -26,6 +26,7 @@
 #include "fpc_tree_kernels.h"
 #include "fpc_tower.h"
 #include "fpc_tower256.h"
+#include "fpc_towerw.h"
 
 namespace fpc {
 
@@ -440,13 +441,14 @@ struct NN {
   float *towerB = nullptr;           // [2*nblocks + 2][256] (128 used)
   bool use_tower = false;            // hidden == 128: k_tower
   int tower_waves = getenv("FPC_TOWER_WAVES") ? atoi(getenv("FPC_TOWER_WAVES")) : 8;   // developer knob (A/B): 4 = one wave per SIMD
-  bool use_tower256 = false;         // hidden == 256: k_tower256w (any board size)
+  bool use_tower256 = false;         // hidden == 256 megakernel: k_towerw<256> (any board size) ...
   bool tower256_v1 = false;          // ... or, FPC_TOWER256_V1=1 on the 14x14 board, round 2's k_tower256
+  bool use_towerw = false;           // k_towerw runs the tower (hidden 256 by default; hidden 128 behind FPC_TOWERW=1)
   void (*mark_fn)(void *, int) = nullptr;   // stage-timing hook of the engine (tag 2 = policy Linear starts)
   void *mark_ctx = nullptr;
   float vb = 0.f;
   // dynamic-LDS opt-ins (hipFuncSetAttribute) already made for this engine's device
-  bool attr_conv[2][3] = {{false, false, false}, {false, false, false}}, attr_tower[2] = {false, false}, attr_tower256[2] = {false, false}, attr_fc[2] = {false, false}, attr_gemv = false;
+  bool attr_conv[2][3] = {{false, false, false}, {false, false, false}}, attr_tower[2] = {false, false}, attr_tower256[2] = {false, false}, attr_towerw[2] = {false, false}, attr_fc[2] = {false, false}, attr_gemv = false;
 
   template <class T>
   int dmalloc(T **p, size_t count, std::string *err) {
@@ -476,7 +478,7 @@ struct NN {
   const fpc_board *in_boards = nullptr;
   const int *in_leaf_slot = nullptr, *in_leaf_turn = nullptr;
   int in_board_stride = 0;
-  bool takes_boards() const { return use_tower || use_tower256; }
+  bool takes_boards() const { return use_tower || use_tower256 || use_towerw; }
   void set_board_input(const fpc_board *b, int stride, const int *slot, const int *turn) { in_boards = b; in_board_stride = stride; in_leaf_slot = slot; in_leaf_turn = turn; }
   uint16_t one16() const { return dtype ? 0x3C00 : 0x3F80; }
   float *logits() { return d_logits; }
@@ -569,11 +571,42 @@ struct NN {
     if ((rc = dmalloc(&d_logits, (size_t)Gmax * dc.A, err))) return rc;
     if ((rc = dmalloc(&d_stats, (size_t)Gmax * SM_MAXCH * SM_REC, err))) return rc;
     if ((rc = dmalloc(&d_value, (size_t)Gmax, err))) return rc;
-    use_tower = false;
-    if (F == 128 && !getenv("FPC_NO_TOWER")) {
+    use_tower = use_tower256 = use_towerw = tower256_v1 = false;
+    const bool no_tower = getenv("FPC_NO_TOWER") != nullptr;
+    auto knob = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
+    // Which megakernel runs the tower (one launch, activations LDS-resident; everything else: k_conv3x3 per layer):
+    //   hidden 256: k_towerw (two waves per SIMD, weights L2 -> registers; any board size).  Developer knob for same-box
+    //               A/Bs: FPC_TOWER256_V1=1 = round 2's k_tower256 (one wave per SIMD, LDS weight ring; 14x14 only).
+    //   hidden 128: k_tower (LDS-DMA weight ring, loader / staggered wave roles).  Developer knob FPC_TOWERW=1 = k_towerw.
+    if (F == 256 && !no_tower) {
+      use_tower256 = true;
+      tower256_v1 = knob("FPC_TOWER256_V1", 0) != 0 && dc.R == 14;
+      use_towerw = !tower256_v1;
+    } else if (F == 128 && !no_tower) {
+      use_towerw = knob("FPC_TOWERW", 0) != 0;
+      use_tower = !use_towerw;
+    }
+    const int layers = 2 * nblocks + 2;
+    if (use_towerw) {
+      // weights in MFMA fragment order [layer][tap][k-step of 32][cout tile of 16][lane][8] (fpc_towerw.h); one slab =
+      // one k-step of one tap = F * 64 bytes; one slab of padding behind the last layer (the prefetch runs one k-step
+      // ahead without a branch); head convolutions zero-padded to F output channels
+      const int slab = tww_slab(F), ksn = F / 32, tiles = F / 16;
+      if ((rc = dmalloc(&towerW, ((size_t)layers * 9 * ksn + 1) * slab, err)) || (rc = dmalloc(&stemW, (size_t)9 * slab, err)) ||
+          (rc = dmalloc(&towerB, (size_t)layers * 256, err))) return rc;
+      auto prep = [&](const ConvW &cw, int layer) {
+        hipLaunchKernelGGL(k_towerw_prep, dim3((9 * ksn * tiles * 64 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)cw.w,
+                           towerW + (size_t)layer * 9 * ksn * slab, 9, cw.cout_pad, F, tiles);
+        (void)hipMemcpyAsync(towerB + (size_t)layer * 256, cw.b, (size_t)std::min(cw.cout_pad, F) * 4, hipMemcpyDeviceToDevice, stream);
+      };
+      for (int i = 0; i < nblocks; ++i) { prep(c1[i], 2 * i); prep(c2[i], 2 * i + 1); }
+      prep(vconv, 2 * nblocks);
+      prep(pconv, 2 * nblocks + 1);
+      hipLaunchKernelGGL(k_towerw_prep, dim3((9 * tiles * 64 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)stem.w, stemW, 9, stem.cout_pad, 32, tiles);
+      if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) { *err = "k_towerw_prep failed"; return FPC_ENODEVICE; }
+    } else if (use_tower) {
       // k_tower streams every tap as one 32 KiB block already laid out as its LDS image (fpc_tower.h);
       // layers: c1[0], c2[0], ..., then the value conv and the policy conv
-      const int layers = 2 * nblocks + 2;
       if ((rc = dmalloc(&towerW, (size_t)(layers * 9 + 3) * TW_TAP, err)) || (rc = dmalloc(&stemW, (size_t)9 * TW_STEM_TAP, err)) ||
           (rc = dmalloc(&towerB, (size_t)layers * 256, err))) return rc;
       auto prep = [&](const ConvW &cw, int layer) {
@@ -586,35 +619,20 @@ struct NN {
       prep(pconv, 2 * nblocks + 1);
       hipLaunchKernelGGL(k_tower_prep, dim3((9 * 128 * 4 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)stem.w, stemW, 9, 32);
       if (hipStreamSynchronize(stream) != hipSuccess) { *err = "k_tower_prep failed"; return FPC_ENODEVICE; }
-      use_tower = true;
-    }
-    use_tower256 = false;
-    if (F == 256 && !getenv("FPC_NO_TOWER")) {
-      // hidden = 256: the whole tower in one launch at every board size.  k_tower256w (default) reads its weights in
-      // MFMA fragment order [layer][tap][k-step][cout tile][lane][8] (one slab = one 32-deep k-step of one tap =
-      // 16 KiB; one slab of padding behind the last layer: the prefetch runs one k-step ahead without a branch);
-      // k_tower256 (round 2's one-wave-per-SIMD form, 14x14 only, developer knob FPC_TOWER256_V1=1 for same-box A/Bs)
-      // streams the same slabs in LDS-image order.  Head convolutions are zero-padded to 256 output channels.
-      tower256_v1 = getenv("FPC_TOWER256_V1") != nullptr && atoi(getenv("FPC_TOWER256_V1")) != 0 && dc.R == 14;
-      const int layers = 2 * nblocks + 2;
-      if ((rc = dmalloc(&towerW, ((size_t)layers * 9 * T2_KS + 1) * T2_SLAB, err)) || (rc = dmalloc(&stemW, (size_t)9 * T2_SLAB, err)) ||
+    } else if (tower256_v1) {
+      // k_tower256 streams one 16 KiB slab per k-step ([256 cout][32 cin], LDS-image order, fpc_tower256.h)
+      if ((rc = dmalloc(&towerW, (size_t)layers * 9 * T2_KS * T2_SLAB, err)) || (rc = dmalloc(&stemW, (size_t)9 * T2_SLAB, err)) ||
           (rc = dmalloc(&towerB, (size_t)layers * 256, err))) return rc;
       auto prep = [&](const ConvW &cw, int layer) {
-        if (tower256_v1)
-          hipLaunchKernelGGL(k_tower256_prep, dim3((9 * T2_KS * 256 * 4 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)cw.w,
-                             towerW + (size_t)layer * 9 * T2_KS * T2_SLAB, 9, cw.cout_pad);
-        else
-          hipLaunchKernelGGL(k_tower256w_prep, dim3((9 * T2_KS * 16 * 64 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)cw.w,
-                             towerW + (size_t)layer * 9 * T2_KS * T2_SLAB, 9, cw.cout_pad);
+        hipLaunchKernelGGL(k_tower256_prep, dim3((9 * T2_KS * 256 * 4 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)cw.w,
+                           towerW + (size_t)layer * 9 * T2_KS * T2_SLAB, 9, cw.cout_pad);
         (void)hipMemcpyAsync(towerB + (size_t)layer * 256, cw.b, (size_t)std::min(cw.cout_pad, 256) * 4, hipMemcpyDeviceToDevice, stream);
       };
       for (int i = 0; i < nblocks; ++i) { prep(c1[i], 2 * i); prep(c2[i], 2 * i + 1); }
       prep(vconv, 2 * nblocks);
       prep(pconv, 2 * nblocks + 1);
-      if (tower256_v1) hipLaunchKernelGGL(k_tower256_prep_stem, dim3((9 * 256 * 4 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)stem.w, stemW);
-      else hipLaunchKernelGGL(k_tower256w_prep_stem, dim3((9 * 16 * 64 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)stem.w, stemW);
-      if (hipStreamSynchronize(stream) != hipSuccess || hipGetLastError() != hipSuccess) { *err = "k_tower256 weight preparation failed"; return FPC_ENODEVICE; }
-      use_tower256 = true;
+      hipLaunchKernelGGL(k_tower256_prep_stem, dim3((9 * 256 * 4 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)stem.w, stemW);
+      if (hipStreamSynchronize(stream) != hipSuccess) { *err = "k_tower256_prep failed"; return FPC_ENODEVICE; }
     }
     loaded = true;
     return 0;
@@ -660,7 +678,7 @@ struct NN {
       return launch_conv<DT>(g, M, err);
     };
     int cur = 0;
-    if (use_tower || use_tower256) {
+    if (use_tower || use_tower256 || use_towerw) {
       TowerArgs t{};
       t.boards = in_boards; t.leaf_slot = in_leaf_slot; t.leaf_turn = in_leaf_turn; t.board_stride = in_board_stride; t.one16 = one16();
       in_boards = nullptr;
@@ -687,21 +705,26 @@ struct NN {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 7, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
         attr = true;
       }
-      if (use_tower256) {
-        bool &a256 = attr_tower256[DT];
-        if (!a256) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower256<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
-          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower256w<DT, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS);
-          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower256w<DT, 5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS);
-          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower256w<DT, 7, false>), hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS);
-          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower256w<DT, 7, true>), hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS);
-          a256 = true;
+      if (use_towerw) {
+        bool &aw = attr_towerw[DT];
+        if (!aw) {
+#define FPC_TWW_ATTR(F_, MT_, FAST_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_towerw<DT, F_, MT_, FAST_>), hipFuncAttributeMaxDynamicSharedMemorySize, tww_lds(F_))
+          FPC_TWW_ATTR(256, 3, false); FPC_TWW_ATTR(256, 5, false); FPC_TWW_ATTR(256, 7, false); FPC_TWW_ATTR(256, 7, true);
+          FPC_TWW_ATTR(128, 3, false); FPC_TWW_ATTR(128, 5, false); FPC_TWW_ATTR(128, 7, false); FPC_TWW_ATTR(128, 7, true);
+#undef FPC_TWW_ATTR
+          aw = true;
         }
-        if (tower256_v1) hipLaunchKernelGGL((k_tower256<DT>), dim3(n), dim3(TW_THREADS), T2_LDS, stream, t);
-        else if (mt == 3) hipLaunchKernelGGL((k_tower256w<DT, 3, false>), dim3(n), dim3(T3_THREADS), T3_LDS, stream, t);
-        else if (mt == 5) hipLaunchKernelGGL((k_tower256w<DT, 5, false>), dim3(n), dim3(T3_THREADS), T3_LDS, stream, t);
-        else if (P != 16) hipLaunchKernelGGL((k_tower256w<DT, 7, false>), dim3(n), dim3(T3_THREADS), T3_LDS, stream, t);
-        else hipLaunchKernelGGL((k_tower256w<DT, 7, true>), dim3(n), dim3(T3_THREADS), T3_LDS, stream, t);
+#define FPC_TWW_GO(F_, MT_, FAST_) hipLaunchKernelGGL((k_towerw<DT, F_, MT_, FAST_>), dim3(n), dim3(TWW_THREADS), tww_lds(F_), stream, t)
+        if (F == 256) {
+          if (mt == 3) FPC_TWW_GO(256, 3, false); else if (mt == 5) FPC_TWW_GO(256, 5, false); else if (P != 16) FPC_TWW_GO(256, 7, false); else FPC_TWW_GO(256, 7, true);
+        } else {
+          if (mt == 3) FPC_TWW_GO(128, 3, false); else if (mt == 5) FPC_TWW_GO(128, 5, false); else if (P != 16) FPC_TWW_GO(128, 7, false); else FPC_TWW_GO(128, 7, true);
+        }
+#undef FPC_TWW_GO
+      } else if (tower256_v1) {
+        bool &a256 = attr_tower256[DT];
+        if (!a256) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower256<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS); a256 = true; }
+        hipLaunchKernelGGL((k_tower256<DT>), dim3(n), dim3(TW_THREADS), T2_LDS, stream, t);
       } else if (mt == 3 && tower_waves == 8) hipLaunchKernelGGL((k_tower<DT, 3, false, 8>), dim3(n), dim3(512), TW_LDS, stream, t);
       else if (mt == 3) hipLaunchKernelGGL((k_tower<DT, 3, false, 4>), dim3(n), dim3(256), TW_LDS, stream, t);
       else if (mt == 5 && tower_waves == 8) hipLaunchKernelGGL((k_tower<DT, 5, false, 8>), dim3(n), dim3(512), TW_LDS, stream, t);
@@ -725,7 +748,7 @@ struct NN {
       }
 #endif
     } else if ((rc = conv(stem, in16, 32, nullptr, act[0], F, F, 0))) return rc;
-    const bool fused = use_tower || use_tower256;
+    const bool fused = use_tower || use_tower256 || use_towerw;
     for (int i = 0; i < nblocks && !fused; ++i) {
       const int t1 = (cur + 1) % 3, t2 = (cur + 2) % 3;
       if ((rc = conv(c1[i], act[cur], F, nullptr, act[t1], F, F, 0))) return rc;

@@ -475,7 +475,7 @@ def main():
     shape_key = "r%d_b%d_h%d_g%d" % (R, Nb, F, G)
     tower_desc = {"k_tower": "k_tower (residual tower megakernel, hidden 128, LDS-resident activations)",
                   "k_tower256": "k_tower256 (residual tower megakernel, hidden 256, one wave per SIMD, 2-slab LDS weight ring; developer knob)",
-                  "k_tower256w": "k_tower256w (residual tower megakernel, hidden 256, two waves per SIMD, weights L2 -> registers, LDS-resident activations)",
+                  "k_towerw": "k_towerw (residual tower megakernel, hidden %d, two waves per SIMD, weights L2 -> registers, LDS-resident activations)" % F,
                   "k_conv3x3": "k_conv3x3 x %d launches (per-layer implicit GEMM, activations through L2) + k_value_tail" % (2 * Nb + 3)}.get(nn_kernel, nn_kernel)
     fc_kernels = ["k_fc16" if weights.FC_LAYOUT == 1 else "k_fc", "k_fc_reduce"]   # the Linear (by the weight layout exported) and its split-K reduce
     tree_ms = sel_ms + exp_ms

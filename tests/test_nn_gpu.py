@@ -82,7 +82,7 @@ def _positions(R, n):
                                                        (14, 2, 64, 1, 1e-3), (14, 2, 64, 0, 8e-3),
                                                        (14, 3, 128, 1, 1e-3), (14, 3, 128, 0, 8e-3), (8, 3, 128, 0, 8e-3),
                                                        (8, 2, 256, 1, 1e-3), (10, 2, 128, 1, 1e-3),
-                                                       # hidden 256: k_tower256w at every row-tile variant (MT 3 / 5 / 7 generic / 7 fast)
+                                                       # hidden 256: k_towerw at every row-tile variant (MT 3 / 5 / 7 generic / 7 fast)
                                                        (8, 3, 256, 0, 8e-3), (10, 2, 256, 1, 1e-3), (11, 2, 256, 1, 1e-3), (12, 2, 256, 1, 1e-3),
                                                        (13, 2, 256, 1, 1e-3), (14, 2, 256, 1, 1e-3), (14, 2, 256, 0, 8e-3),
                                                        # sizes without a reference layout: every k_tower row-tile variant
@@ -141,9 +141,38 @@ def test_tower_wave_forms_give_identical_bits(R, blocks, monkeypatch):
         assert np.abs(outs[0][0]).mean() > 1e-3
 
 
+@pytest.mark.parametrize("R,blocks", [(14, 3), (8, 3), (10, 2), (13, 2)])
+def test_towerw_and_tower_give_identical_bits_at_hidden_128(R, blocks, monkeypatch):
+    """k_towerw<128> (two waves per SIMD, weights L2 -> registers, no barrier inside a layer; developer knob FPC_TOWERW=1)
+    against k_tower (LDS-DMA weight ring, the default at hidden 128): same MFMAs on the same operands in the same order
+    per output element -> logits and values bit for bit, both operand types, every row-tile variant (MT 3 / 5 / 7)."""
+    import torch
+    import weights
+    m = _model(R, blocks, 128, seed=8)
+    G = 40
+    x = (torch.rand(G, 24, R, R, generator=torch.Generator().manual_seed(R + 1)) < 0.1).float().cuda()
+    for dtype in (1, 0):
+        outs = []
+        for w in ("0", "1"):
+            monkeypatch.setenv("FPC_TOWERW", w)
+            eng = make_engine("gpu", R, INV_OF[R], max_games=G, max_sims=4, nn_dtype=dtype)
+            eng.load_weights(weights.export_weights(m, dtype))
+            assert (eng.L.fpc_nn_kernel(eng.h) or b"").decode() == ("k_towerw" if w == "1" else "k_tower")
+            lg = torch.empty(G, eng.A, device="cuda")
+            va = torch.empty(G, device="cuda")
+            for _ in range(2):
+                eng.nn_forward(x.data_ptr(), G, lg.data_ptr(), va.data_ptr())
+            torch.cuda.synchronize()
+            outs.append((lg.cpu().numpy().copy(), va.cpu().numpy().copy()))
+            eng.close()
+        monkeypatch.delenv("FPC_TOWERW")
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), (R, dtype)
+        assert np.abs(outs[0][0]).mean() > 1e-3
+
+
 @pytest.mark.parametrize("dtype", [1, 0], ids=["fp16", "bf16"])
 def test_tower256_forms_give_identical_bits(dtype, monkeypatch):
-    """k_tower256w (round 4: two waves per SIMD, weights straight from L2 into registers, no barrier inside a layer) and
+    """k_towerw at hidden 256 (round 4: two waves per SIMD, weights straight from L2 into registers, no barrier inside a layer) and
     k_tower256 (round 2's one wave per SIMD with the 2-slab LDS ring; developer knob FPC_TOWER256_V1=1, 14x14 only) run
     the same MFMAs on the same operands in the same order for every output element: logits and values must agree BIT FOR
     BIT -- for network inputs given as planes and for the fused leaf encode (a short search)."""
@@ -158,7 +187,7 @@ def test_tower256_forms_give_identical_bits(dtype, monkeypatch):
         monkeypatch.setenv("FPC_TOWER256_V1", v1)
         eng = make_engine("gpu", R, INV_OF[R], max_games=G, max_sims=24, nn_dtype=dtype)
         eng.load_weights(weights.export_weights(m, dtype))
-        assert (eng.L.fpc_nn_kernel(eng.h) or b"").decode() == ("k_tower256" if v1 == "1" else "k_tower256w")
+        assert (eng.L.fpc_nn_kernel(eng.h) or b"").decode() == ("k_tower256" if v1 == "1" else "k_towerw")
         lg = torch.empty(G, eng.A, device="cuda")
         va = torch.empty(G, device="cuda")
         for _ in range(2):

@@ -431,6 +431,168 @@ __device__ __attribute__((noinline)) bool attacked_virtual(const fpc_board *b, c
   return hit;
 }
 
+// ---- king-safety tables: IsKingSafeAfterMove (board.cpp:59-68) for ALL pseudo-legal moves of a position at once ----
+// attacked_virtual above answers "is square K attacked after this move" from scratch: 44 probes and ~1 000 VALU
+// instructions per move, on every lane.  But for the moves of one position almost everything is shared: the king
+// stands on the same square K for every move that is not a king move, and such a move changes the board on two squares
+// only.  So the wave looks at K ONCE:
+//   * the enemy leapers (knight / pawn / king, IsAttackedByTeam's probe squares, engine/board.cpp:676-772) that attack K
+//     now: their number and, if it is one, its square -- a move of another piece removes such an attack only by
+//     capturing that piece;
+//   * per ray d from K (rook-type rays end at the ARRAY edge, bishop-type rays at the first illegal location, exactly
+//     as in engine/board.cpp:632 / :658): the distance of the first and of the second piece on it and whether each is an
+//     enemy slider of the ray's type -- a move changes what K sees along a ray only by interposing on / capturing along
+//     that ray (the mover becomes the first piece: the mover's side never attacks its own king) or by taking the FIRST
+//     piece off it (the second one becomes visible).
+// A lane then decides its move with a few compares (ks_move_leaves_king_attacked).  King moves -- K itself changes --
+// are decided by eight lanes each, one per ray / leaper offset (ks_king_moves).  Castling (never generated through the
+// reference's Python boundary) and positions judged for a player of the other team than the mover keep the
+// generic test.  Every decision equals attacked_virtual's: same squares, same bounds, same piece tests.
+__device__ __forceinline__ void ray_dir(int d, int *ri, int *ci) {            // attacked_virtual's ray numbering
+  *ri = d < 4 ? (d == 0 ? -1 : d == 1 ? 1 : 0) : ((d & 2) ? 1 : -1);
+  *ci = d < 4 ? (d == 2 ? -1 : d == 3 ? 1 : 0) : ((d & 1) ? 1 : -1);
+}
+// ray (0..7, or -1) and distance of square (r, c) as seen from (kr, kc); branch-free
+__device__ __forceinline__ int ray_of(int kr, int kc, int r, int c, int *dist) {
+  const int dr = r - kr, dc = c - kc;
+  const int ar = dr < 0 ? -dr : dr, ac = dc < 0 ? -dc : dc;
+  int d = -1;
+  d = ((dc == 0) & (dr != 0)) ? (dr < 0 ? 0 : 1) : d;
+  d = ((dr == 0) & (dc != 0)) ? (dc < 0 ? 2 : 3) : d;
+  d = ((ar == ac) & (ar != 0)) ? 4 + (dr > 0 ? 2 : 0) + (dc > 0 ? 1 : 0) : d;
+  *dist = ar > ac ? ar : ac;
+  return d;
+}
+__device__ __forceinline__ bool enemy_slider(uint8_t p, int d, int team) {
+  const uint8_t tkey = (uint8_t)(0x80 | (team << 5));
+  return ((p & 0xBC) == (uint8_t)(tkey | ((d < 4 ? ROOK : BISHOP) << 2))) | ((p & 0xBC) == (uint8_t)(tkey | (QUEEN << 2)));
+}
+// leaper probe k (0..7 knight, 8..11 pawn, 12..19 king) of square (kr, kc): the probed square or -1, as attacked_virtual
+__device__ __forceinline__ int leaper_square(const DevCfg &c, int kr, int kc, int k) {
+  int r, cc;
+  bool in;
+  if (k < 8) {
+    const int dr = (k & 4) ? ((k & 2) ? 1 : -1) : ((k & 2) ? 2 : -2);
+    const int dc = (k & 4) ? ((k & 1) ? 2 : -2) : ((k & 1) ? 1 : -1);
+    r = kr + dr; cc = kc + dc; in = legal_loc(c, r, cc);
+  } else if (k < 12) {
+    const int j = k - 8;
+    r = (j >> 1) ? kr + 1 : kr - 1; cc = (j & 1) ? kc + 1 : kc - 1; in = in_array(c, r, cc);
+  } else {
+    const int j = k - 12, kk = j < 4 ? j : j + 1;
+    r = kr + kk / 3 - 1; cc = kc + kk % 3 - 1; in = legal_loc(c, r, cc);
+  }
+  return in ? r * c.R + cc : -1;
+}
+// does piece byte p on leaper probe k attack the probed-from square for `team`?  (engine/board.cpp:676-772)
+__device__ __forceinline__ bool leaper_attacks(uint8_t p, int k, int team) {
+  const uint8_t tkey = (uint8_t)(0x80 | (team << 5));
+  if (k < 8) return (p & 0xBC) == (uint8_t)(tkey | (KNIGHT << 2));
+  if (k >= 12) return (p & 0xBC) == (uint8_t)(tkey | (KING << 2));
+  const int j = k - 8, pr = j >> 1, pc = j & 1, col = colour_of(p);
+  const bool att = ((col == 0) & (pr != 0)) | ((col == 1) & (pc == 0)) | ((col == 2) & (pr == 0)) | ((col == 3) & (pc != 0));
+  return ((p & 0xBC) == (uint8_t)(tkey | (PAWN << 2))) & att;
+}
+struct KingSafety {
+  int kr, kc;          // the king's square K
+  uint32_t ray;        // THIS lane's copy of ray (lane & 7): d1 | d2 << 4 | len << 8 | a1 << 12 | a2 << 13  (fetch another ray's with __shfl)
+  int abase;           // bit d: the first piece on ray d is an enemy slider of that ray's type (wave-uniform)
+  int nla, sqla;       // enemy leapers attacking K now; the square of the only one when nla == 1 (wave-uniform)
+};
+// All 64 lanes call.  K must be a square of the board.
+__device__ __forceinline__ KingSafety ks_build(const fpc_board *b, const DevCfg &c, int K, int team) {
+  const int lane = lane_id(), R = c.R;
+  KingSafety ks;
+  ks.kr = row_of(c, K); ks.kc = K - ks.kr * R;
+  // rays: lane (d, k) looks at distances k + 1 and k + 9 of ray d
+  {
+    const int d = lane >> 3, k = lane & 7;
+    int ri, ci;
+    ray_dir(d, &ri, &ci);
+    const int r1 = ks.kr + ri * (k + 1), c1 = ks.kc + ci * (k + 1), r2 = ks.kr + ri * (k + 9), c2 = ks.kc + ci * (k + 9);
+    const bool in1 = d < 4 ? in_array(c, r1, c1) : legal_loc(c, r1, c1);
+    const bool in2 = (k < 5) & (d < 4 ? in_array(c, r2, c2) : legal_loc(c, r2, c2));
+    const uint8_t p1 = b->sq[in1 ? r1 * R + c1 : K], p2 = b->sq[in2 ? r2 * R + c2 : K];
+    const unsigned long long Bin1 = __ballot(in1), Bin2 = __ballot(in2);
+    const unsigned long long Boc1 = __ballot(in1 & present(p1)), Boc2 = __ballot(in2 & present(p2));
+    // every lane assembles ray dd = lane & 7 (the eight copies are identical; lane dd < 8 is the one others fetch)
+    const int dd = lane & 7;
+    const uint32_t in13 = (uint32_t)((Bin1 >> (8 * dd)) & 0xFFull) | ((uint32_t)((Bin2 >> (8 * dd)) & 0x1Full) << 8);
+    const uint32_t oc13 = (uint32_t)((Boc1 >> (8 * dd)) & 0xFFull) | ((uint32_t)((Boc2 >> (8 * dd)) & 0x1Full) << 8);
+    const int len = __builtin_ctz(~in13);                       // squares up to the first one that is out of range (<= 13)
+    const uint32_t oc = oc13 & ((1u << len) - 1u);
+    const int d1 = oc ? __builtin_ctz(oc) + 1 : 0;
+    const uint32_t oc2 = oc & (oc - 1u);
+    const int d2 = oc2 ? __builtin_ctz(oc2) + 1 : 0;
+    int rdi, cdi;
+    ray_dir(dd, &rdi, &cdi);
+    const uint8_t q1 = b->sq[d1 ? (ks.kr + rdi * d1) * R + ks.kc + cdi * d1 : K];
+    const uint8_t q2 = b->sq[d2 ? (ks.kr + rdi * d2) * R + ks.kc + cdi * d2 : K];
+    const bool a1 = (d1 != 0) & enemy_slider(q1, dd, team), a2 = (d2 != 0) & enemy_slider(q2, dd, team);
+    ks.ray = (uint32_t)d1 | ((uint32_t)d2 << 4) | ((uint32_t)len << 8) | (a1 ? 1u << 12 : 0u) | (a2 ? 1u << 13 : 0u);
+    ks.abase = (int)(__ballot(a1) & 0xFFull);                   // lanes 0..7 hold rays 0..7
+  }
+  // leapers: lane k < 20 owns probe k
+  {
+    const int q = lane < 20 ? leaper_square(c, ks.kr, ks.kc, lane) : -1;
+    const uint8_t p = b->sq[q < 0 ? K : q];
+    const bool att = (q >= 0) && leaper_attacks(p, lane, team);
+    const unsigned long long B = __ballot(att);
+    ks.nla = __popcll(B);
+    ks.sqla = __shfl(q, B ? (int)__ffsll((long long)B) - 1 : 0);
+  }
+  return ks;
+}
+// Is K attacked after the move f -> t of a piece of K's own side that is not K itself (no rook hop)?  All lanes call
+// (the ray records travel by __shfl); lanes without a move pass any squares and ignore the answer.
+__device__ __forceinline__ bool ks_move_leaves_king_attacked(const KingSafety &ks, const DevCfg &c, int f, int t) {
+  const int R = c.R;
+  const int fr = row_of(c, f), fc = f - fr * R, tr = row_of(c, t), tc = t - tr * R;
+  int dt, df;
+  const int rt = ray_of(ks.kr, ks.kc, tr, tc, &dt), rf = ray_of(ks.kr, ks.kc, fr, fc, &df);
+  const uint32_t pt = __shfl(ks.ray, rt < 0 ? 0 : rt), pf = __shfl(ks.ray, rf < 0 ? 0 : rf);
+  int att = ks.abase;
+  {   // the mover lands on ray rt in front of (or on) its first piece: it is the first piece now
+    const int d1 = (int)(pt & 15u), len = (int)((pt >> 8) & 15u);
+    const bool blocks = (rt >= 0) & (dt <= len) & ((d1 == 0) | (dt <= d1));
+    att = blocks ? att & ~(1 << (rt < 0 ? 0 : rt)) : att;
+  }
+  {   // the mover WAS the first piece of ray rf and leaves the ray: the second piece shows
+    const int d1 = (int)(pf & 15u);
+    const bool opens = (rf >= 0) & (d1 != 0) & (df == d1) & (rt != rf);
+    att = (opens & (((pf >> 13) & 1u) != 0u)) ? att | (1 << (rf < 0 ? 0 : rf)) : att;
+  }
+  const bool leaper = (ks.nla >= 2) | ((ks.nla == 1) & (t != ks.sqla));
+  return (att != 0) | leaper;
+}
+// Up to eight king moves f -> T_j at once: lane (j, d) walks ray d from T_j (with f emptied) and probes leaper offsets
+// d of the knight / king patterns and d < 4 of the pawn pattern.  tsq: T_j of slot j = lane >> 3, or -1 (empty slot).
+// Returns the ballot of "attacks T_j" over all lanes: slot j's answer is bits 8 j .. 8 j + 7 != 0.  All lanes call.
+__device__ __forceinline__ unsigned long long ks_king_moves(const fpc_board *b, const DevCfg &c, int f, int tsq, int team) {
+  const int lane = lane_id(), R = c.R, d = lane & 7;
+  bool hit = false;
+  if (tsq >= 0) {
+    const int tr = row_of(c, tsq), tc = tsq - tr * R;
+    // leapers: three independent probes
+    const int qn = leaper_square(c, tr, tc, d), qk = leaper_square(c, tr, tc, 12 + d), qp = d < 4 ? leaper_square(c, tr, tc, 8 + d) : -1;
+    const uint8_t pn = b->sq[qn < 0 ? tsq : qn], pk = b->sq[qk < 0 ? tsq : qk], pp = b->sq[qp < 0 ? tsq : qp];
+    hit |= (qn >= 0) & (qn != f) && leaper_attacks(pn, d, team);
+    hit |= (qk >= 0) & (qk != f) && leaper_attacks(pk, 12 + d, team);
+    hit |= (qp >= 0) & (qp != f) && leaper_attacks(pp, 8 + (d & 3), team);
+    // the ray: first piece on the board with f emptied (the king now stands on tsq itself)
+    int ri, ci;
+    ray_dir(d, &ri, &ci);
+    int r = tr + ri, cc = tc + ci;
+    while (d < 4 ? in_array(c, r, cc) : legal_loc(c, r, cc)) {
+      const int q = r * R + cc;
+      const uint8_t p = q == f ? (uint8_t)0 : b->sq[q];
+      if (present(p)) { hit |= enemy_slider(p, d, team); break; }
+      r += ri; cc += ci;
+    }
+  }
+  return __ballot(hit);
+}
+
 // Generator slot `d` (0..7) of a piece, as data: a start square, a step and what a target square may
 // hold.  The reference's generators -- pawn {fwd1, fwd2, capture-, capture+} (engine/board.cpp:97-177),
 // knight (:179-207, loop bound invalid_area = quirk Q8), bishop (:240-254), rook (:256-302), queen =
@@ -615,23 +777,61 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
   if (lane < 48) { s->lk[0][lane] = -1; s->lk[1][lane] = -1; }
   __syncthreads();
 
-  // ---- legality: lane i tests move i on the virtual post-move board (IsKingSafeAfterMove, board.cpp:59-68)
+  // ---- legality (IsKingSafeAfterMove, board.cpp:59-68): lane i decides move i.  The player's king square is looked
+  //      at once for the whole position (ks_build); a move of another piece is then a few compares, king moves take
+  //      eight lanes each (ks_king_moves); castling and "judged for the other team" keep attacked_virtual.
   const int enemy = team_of_colour(player) ^ 1;
+  const int K0 = b->king[player];
+  const bool tables = (K0 != FPC_NO_SQ) & (team_of_colour(turn) == team_of_colour(player));   // wave-uniform
+  KingSafety ks{};
+  if (tables) ks = ks_build(b, c, K0, enemy);
   int nlegal = 0, first = -1;
   for (int base_i = 0; base_i < M; base_i += 64) {
     const int i = base_i + lane;
     bool legal = false;
     int f = 0, t = 0;
+    bool king_move = false, generic = false;
+    uint32_t w = 0;
+    uint8_t mover = 0;
     if (i < M) {
-      const uint32_t w = s->mw[i];
+      w = s->mw[i];
       f = s->mfrom[i]; t = mv_to(w);
-      const uint8_t mover = b->sq[f];
-      int ksq = b->king[player];
-      if (type_of(mover) == KING && colour_of(mover) == player) ksq = t;
-      else if (ksq == t) ksq = FPC_NO_SQ;               // the player's king itself was captured
-      const int rf = mv_rook(w);                        // castling: the rook hops next to the king
-      const int rt = rf == FPC_NO_SQ ? FPC_NO_SQ : f + (t - f) / 2;
-      legal = ksq == FPC_NO_SQ ? true : !attacked_virtual(b, c, f, t, mover, rf, rt, rf == FPC_NO_SQ ? (uint8_t)0 : b->sq[rf], ksq, enemy);
+      mover = b->sq[f];
+      king_move = (type_of(mover) == KING) & (colour_of(mover) == player);
+      generic = !tables | (mv_rook(w) != FPC_NO_SQ);
+      if (K0 == FPC_NO_SQ) { legal = true; generic = false; king_move = false; }   // no king to protect (the reference's ksq test never runs)
+    }
+    if (tables) {
+      // moves of the other pieces: the tables
+      const bool att = ks_move_leaves_king_attacked(ks, c, f, t);
+      if (i < M && !king_move && !generic) legal = !att;
+      // king moves (without the rook hop): slot j = rank among this chunk's king moves, eight lanes per slot
+      const unsigned long long kb = __ballot(i < M && king_move && !generic);
+      if (kb) {                                                  // wave-uniform
+        const int myslot = __popcll(kb & ((1ull << lane) - 1ull));
+        if ((kb >> lane) & 1ull) { if (myslot < 8) s->lk[0][myslot] = t | (f << 8); }   // lk is cleared again below
+        __syncthreads();
+        const int j = lane >> 3, nk = __popcll(kb);
+        const int ent = j < nk && j < 8 ? s->lk[0][j] : -1;
+        const unsigned long long hb = ks_king_moves(b, c, ent < 0 ? 0 : (ent >> 8), ent < 0 ? -1 : (ent & 255), enemy);
+        __syncthreads();
+        if ((kb >> lane) & 1ull) {
+          if (myslot < 8) legal = ((hb >> (8 * myslot)) & 0xFFull) == 0ull;
+          else generic = true;                                   // more than eight king moves in one chunk: cannot happen (8 steps), kept total
+        }
+        if (lane < 8) s->lk[0][lane] = -1;
+        __syncthreads();
+      }
+    }
+    if (__ballot(generic)) {                                     // wave-uniform guard around the out-of-line generic test
+      if (generic) {
+        int ksq = K0;
+        if (king_move) ksq = t;
+        else if (ksq == t) ksq = FPC_NO_SQ;                      // the player's king itself was captured
+        const int rf = mv_rook(w);                               // castling: the rook hops next to the king
+        const int rt = rf == FPC_NO_SQ ? FPC_NO_SQ : f + (t - f) / 2;
+        legal = ksq == FPC_NO_SQ ? true : !attacked_virtual(b, c, f, t, mover, rf, rt, rf == FPC_NO_SQ ? (uint8_t)0 : b->sq[rf], ksq, enemy);
+      }
     }
     const unsigned long long bal = __ballot(legal);
     if (legal) {

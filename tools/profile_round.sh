@@ -16,11 +16,11 @@ stats() {   # stats <name> <bench flags...>
   echo "== $name"; head -8 gpurun_out/$TAG/${name}_kernel_stats.csv | cut -d, -f1-5; cut -c1-300 gpurun_out/$TAG/${name}_bench.json
 }
 if [[ $PART == *A* ]]; then
-stats default --no-cpu-baseline --no-alt-policy-head --no-alt-dtype
+stats default --no-cpu-baseline --no-alt-policy-head --no-alt-dtype --no-dropin
 bash tools/pmc_nn.sh > gpurun_out/$TAG/pmc_nn.log 2>&1; tail -20 gpurun_out/$TAG/pmc_nn.log | cut -c1-400
 for p in a b c d e f; do cp gpurun_out/pmc_$p/*/*counter_collection.csv gpurun_out/$TAG/pmc_$p.csv 2>/dev/null; done
 python3 tools/pmc_summary.py gpurun_out/$TAG r14_b10_h128_g256 > gpurun_out/$TAG/pmc_summary_c1.txt 2>&1
-# the same passes over configs[3]'s network (k_tower256): bench.py prices a kernel only with its own counters
+# the same passes over configs[3]'s network (k_towerw at hidden 256): bench.py prices a kernel only with its own counters
 mkdir -p gpurun_out/$TAG/c3
 PMC_TAG=c3_ FPC_NN_BLOCKS=20 FPC_NN_HIDDEN=256 bash tools/pmc_nn.sh > gpurun_out/$TAG/pmc_nn_c3.log 2>&1; tail -8 gpurun_out/$TAG/pmc_nn_c3.log | cut -c1-300
 for p in a b c d e f; do cp gpurun_out/pmc_c3_$p/*/*counter_collection.csv gpurun_out/$TAG/c3/pmc_$p.csv 2>/dev/null; done
@@ -28,8 +28,10 @@ python3 tools/pmc_summary.py gpurun_out/$TAG/c3 r14_b20_h256_g256 > gpurun_out/$
 cp profiles/pmc_summary.json gpurun_out/$TAG/pmc_summary.json
 fi
 if [[ $PART == *B* ]]; then
-stats config3 --config 3 --steps 3 --warmup 1 --no-cpu-baseline --no-alt-policy-head --no-alt-dtype
-stats board8 --board 8 --steps 6 --no-cpu-baseline --no-alt-policy-head --no-alt-dtype
+stats config3 --config 3 --steps 3 --warmup 1 --no-cpu-baseline --no-alt-policy-head --no-alt-dtype --no-dropin
+stats board8 --board 8 --steps 6 --no-cpu-baseline --no-alt-policy-head --no-alt-dtype --no-dropin
+# the reference's own shipped default: ResNet(15,256), 100 parallel games x 50 searches, 8x8 EIGHT_SIMPLE (alphazero.py:288-304)
+stats refdefault --config ref --steps 8 --warmup 2 --no-cpu-baseline --no-alt-policy-head --no-alt-dtype --no-dropin
 python3 tools/arena_bench.py > gpurun_out/$TAG/arena_1024.json 2> gpurun_out/$TAG/arena_1024.err; cut -c1-400 gpurun_out/$TAG/arena_1024.json
 bash tools/pmc_fc_mem.sh > gpurun_out/$TAG/pmc_fc_mem.log 2>&1; tail -12 gpurun_out/$TAG/pmc_fc_mem.log | cut -c1-400
 for p in a b c d e f; do cp gpurun_out/pmcm_$p/*/*counter_collection.csv gpurun_out/$TAG/pmcm_$p.csv 2>/dev/null; done

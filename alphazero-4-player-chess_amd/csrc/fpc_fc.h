@@ -353,6 +353,24 @@ __global__ void __launch_bounds__(FC_THREADS, 1) k_fc16(FcArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Round 4, built, measured and NOT kept (same-box A/Bs, both variants bit-identical to k_fc16): the recipe that took the hidden-256 tower from 0.36 to 0.49 of peak (fpc_towerw.h: two waves
+// per SIMD, weights straight from memory into registers three k-steps ahead by counted-vmcnt inline-asm loads, no
+// weight ring in LDS, activations by LDS-DMA as here) does NOT carry over to this Linear:
+//   * k_fc16w, wave = 128 rows x 64 columns (two waves share every weight fragment): 0.364 ms with the non-temporal hint
+//     on the weight loads (the second wave's request misses too: HBM sees the weights twice), 0.307 ms without it;
+//   * k_fc16n, wave = 256 rows x 32 columns (every fragment has one owner, nt kept, twice the activation reads per
+//     MFMA): 0.277-0.292 ms against k_fc16's 0.272-0.280 ms, and k_tower beside it 2 % slower (power).
+// So the issue port is not what holds this kernel (k_fc16's MFMA pipe is idle 48 % of the time WAITING FOR DATA): the
+// bound is the memory side -- 1.17 GB of weights from HBM + 1.1 GB of activation re-reads and 0.13 GB of slab writes
+// through the same L2s.
+// A lesson worth keeping from the one GPU fault of that work: an inline-asm load into a register the compiler considers
+// DEAD (the clamped tail prefetches behind the last k-step) is still in flight when hipcc hands that register to later
+// code -- the epilogue's address arithmetic sat in front of the plain `s_waitcnt vmcnt(0)` statement, a late-landing
+// fragment overwrote a store address, the kernel faulted.  A wait that must cover asm loads has to be TIED to their
+// destination registers ("+v" operands of the s_waitcnt statement), also for loads whose data nobody reads.
+// ------------------------------------------------------------------------------------------------------------
+
 // logits[m][n] = bias[n] + slab[base][m][n%256] + slab[base+1][m][n%256] + ...   (fixed order)
 // Sums a column group's K-split slabs and the bias in fixed order, writes the logits, and -- while the
 // block still holds its 1024 logits of the row in registers -- leaves that chunk's softmax statistics

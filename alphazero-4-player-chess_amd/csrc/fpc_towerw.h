@@ -28,8 +28,8 @@
 //     k_tower's generic one (MT = 3 / 5 / 7 row tiles per wave), so hidden = 256 runs as ONE launch at every board size,
 //     incl. the reference's shipped ResNet(15, 256) on its 8x8 board (alphazero.py:288).
 // Measured (same box, kernel trace): ResNet(20,256) 14x14, 256 leaves: 1.95 ms per launch against k_tower256's 2.74
-// = 1.24 PFLOP/s algorithmic (0.49 of the dense peak; 1.46 PFLOP/s executed incl. the border tiles, which is the rate
-// of a bare MFMA stream at the clock the chip holds under this load).
+// = 1.24 PFLOP/s algorithmic (0.49 of the dense peak; 1.41 PFLOP/s executed incl. the border tiles, within 5 % of a bare
+// MFMA stream at the clock the chip holds under such a load).
 #pragma once
 #include "fpc_tower.h"
 

@@ -179,6 +179,15 @@ __device__ __forceinline__ int rot90_src(int R, int k, int i, int j) {
 // ---- wave helpers -------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// diagnostic builds only (-DFPC_TREE_STAMPS=<block>; tools/tree_stamps.py): s_memtime at the phase boundaries of the
+// tree kernels for ONE game, read back through fpc_debug_tree_stamps.  The product build compiles none of it.
+#ifdef FPC_TREE_STAMPS
+__device__ unsigned long long g_tree_stamps[32];
+#define FPC_TS(I) do { if ((int)blockIdx.x == FPC_TREE_STAMPS && lane_id() == 0) g_tree_stamps[I] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FPC_TS(I) do {} while (0)
+#endif
+
 __device__ __forceinline__ void lds_load_board(WaveLds *s, const fpc_board *g) {
   const uint32_t *src = reinterpret_cast<const uint32_t *>(g);
   uint32_t *dst = reinterpret_cast<uint32_t *>(&s->b);
@@ -539,7 +548,7 @@ __device__ __forceinline__ KingSafety ks_build(const fpc_board *b, const DevCfg 
     const bool att = (q >= 0) && leaper_attacks(p, lane, team);
     const unsigned long long B = __ballot(att);
     ks.nla = __popcll(B);
-    ks.sqla = __shfl(q, B ? (int)__ffsll((long long)B) - 1 : 0);
+    ks.sqla = wave_read(q, B ? (int)__ffsll((long long)B) - 1 : 0);
   }
   return ks;
 }
@@ -749,13 +758,14 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
         if (cnt1 < GEN_SCR) scr1[cnt1++] = (uint32_t)to | ((uint32_t)rook_from << 24);
       });
   }
+  FPC_TS(7);
   // exclusive wave scan of (cnt0+cnt1) in lane order == reference generation order
   int incl = cnt0 + cnt1;
   for (int off = 1; off < 64; off <<= 1) {
     const int v = __shfl_up(incl, off);
     if (lane >= off) incl += v;
   }
-  const int total = __shfl(incl, 63);
+  const int total = wave_read(incl, 63);
   const int base = incl - (cnt0 + cnt1);
   if ((lane & 3) == 0 && p <= FPC_MAX_PL - 1) s->poff[p] = (uint16_t)(base < FPC_MAX_MOVES ? base : FPC_MAX_MOVES);
   if (lane == 0) {
@@ -780,11 +790,13 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
   // ---- legality (IsKingSafeAfterMove, board.cpp:59-68): lane i decides move i.  The player's king square is looked
   //      at once for the whole position (ks_build); a move of another piece is then a few compares, king moves take
   //      eight lanes each (ks_king_moves); castling and "judged for the other team" keep attacked_virtual.
+  FPC_TS(8);
   const int enemy = team_of_colour(player) ^ 1;
   const int K0 = b->king[player];
   const bool tables = (K0 != FPC_NO_SQ) & (team_of_colour(turn) == team_of_colour(player));   // wave-uniform
   KingSafety ks{};
   if (tables) ks = ks_build(b, c, K0, enemy);
+  FPC_TS(9);
   int nlegal = 0, first = -1;
   for (int base_i = 0; base_i < M; base_i += 64) {
     const int i = base_i + lane;
@@ -844,6 +856,7 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
   }
   __syncthreads();
 
+  FPC_TS(10);
   // ---- GetGameResult (engine/board.cpp:891-939)
   int result = FPC_IN_PROGRESS;
   if (do_result) {
@@ -935,6 +948,7 @@ __device__ inline void wave_position_ops(WaveLds *s, const DevCfg &c, bool do_re
   }
   __syncthreads();
 
+  FPC_TS(11);
   // ---- ascending flat order of the legal set (children are created in torch.nonzero order,
   //      mcts.py:84-87): rank sort, promotions are already collapsed to one entry
   if (run_legal) {
@@ -1153,11 +1167,12 @@ __device__ __forceinline__ void backprop_lane0(const Tree &t, size_t nb, int n, 
 // BackpropagateNodes (node.cpp:118-126) along the descent path k_select recorded: path[len-1] is the
 // leaf (+v), its parent gets -v, ... -- every node of the path is touched once, so the lanes of one
 // wave update them independently instead of one lane chasing parent pointers.
-__device__ __forceinline__ void backprop_path(const Tree &t, size_t nb, int g, float v) {
-  const int len = t.path_len[g];
+__device__ __forceinline__ void backprop_path(const Tree &t, size_t nb, int g, float v, int len, int node_of_lane) {
+  // len = path_len[g] and node_of_lane = path[lane] (lane < len, first 64 entries) were fetched by the caller together
+  // with everything else whose address needs no other load
   const int *path = t.path + (size_t)g * t.path_cap;
   for (int k = lane_id(); k < len; k += 64) {
-    const int node = path[k];
+    const int node = k < 64 ? node_of_lane : path[k];
     const float sv = ((len - 1 - k) & 1) ? -v : v;
     t.W[nb + node] += (double)sv;
     t.N[nb + node] += 1;
@@ -1171,22 +1186,27 @@ __device__ inline void select_game(WaveLds &s, const DevCfg &c, const Tree &t, i
   int *const leaf_node = to_next ? t.leaf_node_nx : t.leaf_node;
   int *const leaf_slot = to_next ? t.leaf_slot_nx : t.leaf_slot;
   int *const leaf_turn = to_next ? t.leaf_turn_nx : t.leaf_turn;
-  if (!t.alive[g]) {                        // root already removed from the search (Q5)
+  const size_t nb = (size_t)g * t.node_cap;
+  // Everything whose address depends on no other load goes out FIRST, in one round trip (a lone wave per CU pays the
+  // full memory latency for every dependent load: the chain of round trips, not the arithmetic, is this function's
+  // floor): the liveness flag, the root's fields, the board-pool fill level the leaf materialisation will need.
+  const int is_alive = t.alive[g];
+  int c0 = t.child0[nb], nc = t.nch[nb], Nn = t.N[nb];
+  int slot = t.bslot[nb], parent_slot = -1;        // board-pool slot of node n / of its parent
+  const int nboards0 = t.nboards[g];
+  if (!is_alive) {                          // root already removed from the search (Q5)
     if (lane == 0) { leaf_node[g] = -1; leaf_slot[g] = -1; }
     return;
   }
-  const size_t nb = (size_t)g * t.node_cap;
   // ---- descent: SelectChild (node.cpp:49-78)
   //   ucb_i = W_i/N_i + C * sqrt( log(sqrt(N_parent)) / (1 + N_i) ) * P_i      (fp64, no contraction)
   //   strict '>' from -inf => lowest index wins ties, NaN never wins
   // Every level costs ONE dependent global round trip: the lanes that fetch the children's N/W/P also
-  // fetch each child's (first child, child count, board-pool slot), so the chosen child's own children can
-  // be requested as soon as the argmax is known, and at the leaf both its slot and its parent's are at hand.
-  int n = 0, depth = 0;
+  // fetch each child's (first child, child count, board-pool slot, move), so the chosen child's own children can
+  // be requested as soon as the argmax is known, and at the leaf its slot, its parent's and its move are at hand.
+  int n = 0, depth = 0, leaf_mv = 0xffff;
   bool fail = false;
   int *path = t.path + (size_t)g * t.path_cap;
-  int c0 = t.child0[nb], nc = t.nch[nb], Nn = t.N[nb];
-  int slot = t.bslot[nb], parent_slot = -1;        // board-pool slot of node n / of its parent
   for (;;) {
     if (lane == 0 && depth < t.path_cap) path[depth] = n;
     ++depth;
@@ -1194,12 +1214,12 @@ __device__ inline void select_game(WaveLds &s, const DevCfg &c, const Tree &t, i
     const double L = logtab[Nn];
     const double sqrtNp = sqrt((double)Nn);
     double best = 0.0;
-    int besti = -1, best_c0 = -1, best_nc = 0, best_N = 0, best_slot = -1;
+    int besti = -1, best_c0 = -1, best_nc = 0, best_N = 0, best_slot = -1, best_mv = 0xffff;
     for (int base = 0; base < nc; base += 64) {
       const int i = base + lane;
       double u = 0.0;
       bool valid = false;
-      int Nc = 0, cc0 = -1, cnc = 0, cslot = -1;
+      int Nc = 0, cc0 = -1, cnc = 0, cslot = -1, cmv = 0xffff;
       if (i < nc) {
         Nc = t.N[nb + c0 + i];
         const double Wc = t.W[nb + c0 + i];
@@ -1207,6 +1227,7 @@ __device__ inline void select_game(WaveLds &s, const DevCfg &c, const Tree &t, i
         cc0 = t.child0[nb + c0 + i];
         cnc = t.nch[nb + c0 + i];
         cslot = t.bslot[nb + c0 + i];
+        cmv = t.mv[nb + c0 + i];
         if (c.rules & FPC_RULES_PUCT) {
           // AlphaZero PUCT, the child's value seen from the parent: -W/N + C P sqrt(N_parent) / (1 + N)
           const double q = Nc > 0 ? -(Wc / (double)Nc) : 0.0;
@@ -1218,22 +1239,31 @@ __device__ inline void select_game(WaveLds &s, const DevCfg &c, const Tree &t, i
         }
         valid = u > -__builtin_inf();
       }
-      int idx = valid ? i : 0x7fffffff;
-      if (!valid) u = -__builtin_inf();
-      for (int off = 32; off >= 1; off >>= 1) {
-        const double u2 = __shfl_xor(u, off);
-        const int i2 = __shfl_xor(idx, off);
-        if (u2 > u || (u2 == u && i2 < idx)) { u = u2; idx = i2; }
+      // argmax with the reference's rule (strict '>': the FIRST maximum wins): start at the lowest valid lane and jump
+      // to the lowest lane that beats the current one until none does -- about ln(children) rounds of two scalar lane
+      // reads, a compare and a ballot, instead of six butterfly rounds of three LDS-crossbar shuffles each
+      const unsigned long long live = __ballot(valid);
+      int idx = 0x7fffffff, cur = 0;
+      double ubest = -__builtin_inf();
+      if (live) {                                  // wave-uniform
+        cur = (int)__ffsll((long long)live) - 1;
+        for (;;) {
+          ubest = wave_read(u, cur);
+          const unsigned long long gt = __ballot(valid && u > ubest);
+          if (!gt) break;
+          cur = (int)__ffsll((long long)gt) - 1;
+        }
+        idx = base + cur;
       }
-      const int src = idx != 0x7fffffff ? idx - base : 0;
-      const int w_c0 = __shfl(cc0, src), w_nc = __shfl(cnc, src), w_N = __shfl(Nc, src), w_slot = __shfl(cslot, src);
-      if (idx != 0x7fffffff && (besti < 0 || u > best)) { best = u; besti = idx; best_c0 = w_c0; best_nc = w_nc; best_N = w_N; best_slot = w_slot; }
+      const int w_c0 = wave_read(cc0, cur), w_nc = wave_read(cnc, cur), w_N = wave_read(Nc, cur), w_slot = wave_read(cslot, cur), w_mv = wave_read(cmv, cur);
+      if (idx != 0x7fffffff && (besti < 0 || ubest > best)) { best = ubest; besti = idx; best_c0 = w_c0; best_nc = w_nc; best_N = w_N; best_slot = w_slot; best_mv = w_mv; }
     }
     if (besti < 0) { fail = true; break; }
     n = c0 + besti;
     c0 = best_c0; nc = best_nc; Nn = best_N;
-    parent_slot = slot; slot = best_slot;
+    parent_slot = slot; slot = best_slot; leaf_mv = best_mv;
   }
+  FPC_TS(5);
   if (fail) {                                // node.cpp:72-75 throws
     if (lane == 0) { t.err[g] |= ERR_SELECT; t.alive[g] = 0; leaf_node[g] = -1; leaf_slot[g] = -1; }
     return;
@@ -1244,11 +1274,11 @@ __device__ inline void select_game(WaveLds &s, const DevCfg &c, const Tree &t, i
   if (slot < 0) {
     lds_load_board(&s, &pool[parent_slot]);
     int from;
-    const int to = flat_to(c, t.mv[nb + n], &from);
+    const int to = flat_to(c, leaf_mv, &from);
     const bool moved = make_move_wave(&s.b, from, to, c);
     if (lane == 0) {
       int e = moved ? 0 : ERR_MOVE;
-      int ns = t.nboards[g];
+      int ns = nboards0;                     // fetched with the root's fields; only this block ever changes it
       if (ns >= t.board_cap) { e |= ERR_CAP_BOARDS; ns = -1; } else { t.nboards[g] = ns + 1; t.bslot[nb + n] = ns; }
       s.first_legal = ns;                    // broadcast through LDS
       if (e) t.err[g] |= e;
@@ -1263,9 +1293,11 @@ __device__ inline void select_game(WaveLds &s, const DevCfg &c, const Tree &t, i
   } else {
     lds_load_board(&s, &pool[slot]);
   }
+  FPC_TS(6);
   // ---- GetGameResult (node.cpp:28-29) then, if in progress, GetLegalMoves
   //      (four_player_chess_board.py:38) on the same state, with their list reorderings
   wave_position_ops(&s, c, true, true, -1);
+  FPC_TS(12);
   lds_store_board(&s, &t.boards[(size_t)g * t.board_cap + slot]);
   const int res = s.result;
   if (lane == 0 && s.errbits) t.err[g] |= s.errbits;
@@ -1283,6 +1315,7 @@ __device__ inline void select_game(WaveLds &s, const DevCfg &c, const Tree &t, i
   uint16_t *lg = t.legal + (size_t)g * FPC_MAX_MOVES;
   for (int k = lane; k < nl; k += 64) lg[k] = s.lsorted[k];
   if (lane == 0) { leaf_node[g] = n; leaf_slot[g] = slot; leaf_turn[g] = s.b.turn; t.nlegal[g] = nl; t.path_len[g] = depth; }
+  FPC_TS(13);
 }
 
 __global__ void __launch_bounds__(64) k_select(DevCfg c, Tree t, int G, double Cpuct, const double *logtab) {
@@ -1329,7 +1362,20 @@ __device__ __forceinline__ float fdiv_rn(float a, float b) {
 // Shared end of both expand kernels (one wave): s.pri[0..nl) = unnormalised legal probabilities in
 // ascending flat order, s.lsorted the flat indices.  Legal mass (sequential ascending f32 sum),
 // policy error, BackpropagateNodes (mcts.py:78) before ExpandNodes (mcts.py:79), children appended.
-__device__ __forceinline__ void expand_finish(WaveLds &s, const Tree &t, int g, size_t nb, int n, int nl, bool nan, const float *value) {
+struct ExpandPre {     // what expand_game / expand_legal_game fetch up front for expand_finish (one round trip with their own loads)
+  float v;             // value[g]
+  int path_len, path_node, nnodes;
+};
+__device__ __forceinline__ ExpandPre expand_prefetch(const Tree &t, int g, const float *value) {
+  ExpandPre e;
+  const int lane = lane_id();
+  e.v = value[g];
+  e.path_len = t.path_len[g];
+  e.path_node = lane < t.path_cap ? t.path[(size_t)g * t.path_cap + lane] : 0;
+  e.nnodes = t.nnodes[g];
+  return e;
+}
+__device__ __forceinline__ void expand_finish(WaveLds &s, const Tree &t, int g, size_t nb, int n, int nl, bool nan, const ExpandPre &pre) {
   const int lane = lane_id();
   if (lane == 0) {
     float T = 0.f;
@@ -1359,10 +1405,10 @@ __device__ __forceinline__ void expand_finish(WaveLds &s, const Tree &t, int g, 
   const float SG = s.scal_f;
   const bool add_noise = noisy && SG > 0.f;      // rows without positive mass (never uploaded, all-zero draws) leave the priors alone
   // BackpropagateNodes (mcts.py:78) before ExpandNodes (mcts.py:79)
-  backprop_path(t, nb, g, value[g]);
+  backprop_path(t, nb, g, pre.v, pre.path_len, pre.path_node);
   if (lane == 0) t.sims_done[g] += 1;
   // children: ascending flat order, entries with prior == 0 dropped (torch.nonzero, mcts.py:84)
-  const int base_node = t.nnodes[g];
+  const int base_node = pre.nnodes;
   int created = 0;
   for (int b0 = 0; b0 < nl; b0 += 64) {
     const int j = b0 + lane;
@@ -1456,35 +1502,50 @@ constexpr int EXPAND_THREADS = 64;
 __device__ inline void expand_game(WaveLds &s, const DevCfg &c, const Tree &t, int G, int g, const float *logits, const float *stats,
                                    const float *value) {
   const int lane = lane_id();
-  const int n = t.leaf_node[g];
-  const int turn0 = (c.rules & FPC_RULES_ROTATION) ? t.leaf_turn[g] : first_leaf_turn(t.leaf_node, t.leaf_turn, G);
-  if (n < 0) return;
   const size_t nb = (size_t)g * t.node_cap;
   const float *lg = logits + (size_t)g * c.A;
   const int nchunks = (c.A / 4 + SM_THREADS - 1) / SM_THREADS;     // A = (8R+8)*R*R is a multiple of 4 for even R
   const float *st = stats + (size_t)g * SM_MAXCH * SM_REC;
-  // the legal logits are requested before the statistics are reduced (independent round trips)
-  const int nl = t.nlegal[g];
   const uint16_t *legal = t.legal + (size_t)g * FPC_MAX_MOVES;
+  // ONE round trip for everything whose address depends on no other load (a lone wave per CU pays the full memory
+  // latency per dependent load): the leaf, its legal list (first 64 entries), the chunk records, the leaf turns of the
+  // first 64 games (the batch's first live leaf is almost always among them), value / path / node count.
+  const int n = t.leaf_node[g];
+  const int nl = t.nlegal[g];
+  const int own_turn = t.leaf_turn[g];
+  const int scan_node = lane < G ? t.leaf_node[lane] : -1;
+  const int scan_turn = lane < G ? t.leaf_turn[lane] : 0;
+  const int fl0 = legal[lane];                                    // lane < 64 <= FPC_MAX_MOVES: always in bounds
   float mc = -__builtin_inff(), sc = 0.f;
   bool nan = false;
   if (lane < nchunks) { mc = st[lane * SM_REC]; sc = st[lane * SM_REC + 1]; nan = st[lane * SM_REC + 2] != 0.f; }
+  const ExpandPre pre = expand_prefetch(t, g, value);
+  int turn0;
+  if (c.rules & FPC_RULES_ROTATION) turn0 = own_turn;
+  else {                                                          // the batch's FIRST live leaf (Q6)
+    const unsigned long long bal = __ballot(scan_node >= 0);
+    turn0 = bal ? wave_read(scan_turn, (int)__ffsll((long long)bal) - 1) : (G > 64 ? first_leaf_turn(t.leaf_node, t.leaf_turn, G) : 0);
+  }
+  if (n < 0) return;
+  FPC_TS(1);
   float m = mc;
   for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(m, off); m = o > m ? o : m; }
   nan = __ballot(nan) != 0ull;
   const float term = (lane < nchunks && mc > -__builtin_inff()) ? sc * fpc_expf(mc - m) : 0.f;
   float S = 0.f;
-  for (int k = 0; k < nchunks; ++k) S = S + __shfl(term, k);
+  for (int k = 0; k < nchunks; ++k) S = S + wave_read(term, k);      // sequential ascending sum (numeric spec); k is wave-uniform
   const float inv = fdiv_rn(1.0f, S);
+  FPC_TS(2);
   for (int j = lane; j < nl; j += 64) {
-    const int fl = legal[j];
+    const int fl = j < 64 ? fl0 : (int)legal[j];
     const int plane = fl / c.RR, pos = fl % c.RR;
     const int src = plane * c.RR + rot90_src(c.R, -turn0, pos / c.R, pos % c.R);
     s.pri[j] = fpc_expf(lg[src] - m) * inv;
     s.lsorted[j] = (uint16_t)fl;
   }
   __syncthreads();
-  expand_finish(s, t, g, nb, n, nl, nan, value);
+  FPC_TS(3);
+  expand_finish(s, t, g, nb, n, nl, nan, pre);
 }
 
 __global__ void __launch_bounds__(EXPAND_THREADS) k_expand(DevCfg c, Tree t, int G, const float *logits, const float *stats, const float *value) {
@@ -1503,8 +1564,10 @@ __global__ void __launch_bounds__(EXPAND_THREADS) k_expand_select(DevCfg c, Tree
   __shared__ WaveLds s;
   const int g = blockIdx.x;
   if (g >= G) return;
+  FPC_TS(0);
   expand_game(s, c, t, G, g, logits, stats, value);
   __syncthreads();                           // the new children (global stores of other lanes) are visible to the descent
+  FPC_TS(4);
   select_game(s, c, t, g, Cpuct, logtab, true);
 }
 
@@ -1522,6 +1585,7 @@ __global__ void __launch_bounds__(EXPAND_THREADS) k_expand_select(DevCfg c, Tree
 __device__ inline void expand_legal_game(WaveLds &s, const DevCfg &c, const Tree &t, int g, const float *ll, const float *value) {
   const int lane = lane_id();
   const int n = t.leaf_node[g];
+  const ExpandPre pre = expand_prefetch(t, g, value);
   if (n < 0) return;
   const size_t nb = (size_t)g * t.node_cap;
   const int nl = t.nlegal[g];
@@ -1537,7 +1601,7 @@ __device__ inline void expand_legal_game(WaveLds &s, const DevCfg &c, const Tree
     s.lsorted[j] = legal[j];
   }
   __syncthreads();
-  expand_finish(s, t, g, nb, n, nl, nan, value);
+  expand_finish(s, t, g, nb, n, nl, nan, pre);
 }
 
 __global__ void __launch_bounds__(64) k_expand_legal(DevCfg c, Tree t, int G, const float *ll, const float *value) {

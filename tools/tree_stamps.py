@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Phase times of k_expand_select for ONE game (s_memtime stamps, diagnostic build):
+    hipcc ... -DFPC_TREE_STAMPS=<block> ... -o tools/lib_tree_stamps.so     (tools/tree_stamps.sh builds it here)
+    FPC_ENGINE_LIB=$PWD/tools/lib_tree_stamps.so python3 tools/tree_stamps.py [sims] [board]
+Runs a 256-game search on the internal network and prints, for several points of the search, the stamps of the last
+k_expand_select launch."""
+import ctypes as C, os, sys
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(HERE, "alphazero-4-player-chess_amd"), HERE]
+import numpy as np, torch
+import fpc_ffi, net, positions, weights
+from bench import Spec
+sims = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+R = int(sys.argv[2]) if len(sys.argv) > 2 else 14
+INV = {8: 2, 14: 3}[R]
+G = 256
+torch.manual_seed(0)
+m = net.ResNet(Spec(R), 2, 128, "cpu").eval()
+eng = fpc_ffi.Engine(R, INV, max_games=G, max_sims=sims, nn_dtype=1)
+eng.load_weights(weights.export_weights(m, 1))
+L = C.CDLL(os.environ["FPC_ENGINE_LIB"])
+turn, entries = positions.start_entries(R)
+start = fpc_ffi.pods_of([fpc_ffi.board_from_dict(R, turn, entries)])[0]
+boards = np.repeat(start[None, :], G, axis=0)
+names = {0: "start", 1: "loads back, first-leaf turn", 2: "chunk statistics", 3: "legal priors", 4: "expand_finish (backup, children)",
+         5: "descent", 6: "leaf board", 7: "generation walk", 8: "scan + compaction", 9: "ks_build", 10: "legality",
+         11: "result + reordering", 12: "sort", 13: "stores"}
+eng.search_begin_np(boards, 3.0)
+done = 0
+for chunk in (50, 150, sims - 200):
+    if chunk <= 0:
+        continue
+    eng.search_run(chunk)
+    torch.cuda.synchronize()
+    done += chunk
+    st = (C.c_ulonglong * 32)()
+    assert L.fpc_debug_tree_stamps(st) == 0
+    t = [int(x) for x in st]
+    print("after %d simulations (game %s):" % (done, "FPC_TREE_STAMPS"))
+    prev = t[0]
+    for i in range(1, 14):
+        if t[i] == 0:
+            continue
+        print("  %-34s %6d ticks" % (names[i], t[i] - prev))
+        prev = t[i]
+    print("  total %d ticks (s_memtime; 100 MHz reference clock => x10 ns)" % (t[13] - t[0]))
+eng.search_results()

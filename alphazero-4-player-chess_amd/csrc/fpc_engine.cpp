@@ -515,8 +515,8 @@ int fpc_search_expand_select(fpc_engine *e, const float *logits_dev, const float
   e->sims_issued += 1;
   mark(e, 3);
   launch_partials(e, logits_dev);
-  FPC_LAUNCH(k_expand_select, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, logits_dev, (const float *)e->d_stats, value_dev, e->Cpuct,
-             (const double *)e->d_logtab);
+  FPC_LAUNCH(k_expand_select, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (LogitSrc{logits_dev, nullptr, nullptr, 0, 0, 0, 0}),
+             (const float *)e->d_stats, value_dev, e->Cpuct, (const double *)e->d_logtab);
   HIPCHK(e, hipGetLastError());
   swap_leaf_arrays(e);
   mark(e, 4);
@@ -531,7 +531,7 @@ int fpc_search_expand(fpc_engine *e, const float *logits_dev, const float *value
   if (!logits_dev || !value_dev) return fail(e, FPC_EINVAL, "null logits/value");
   mark(e, 3);
   launch_partials(e, logits_dev);
-  FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, logits_dev, (const float *)e->d_stats, value_dev);
+  FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (LogitSrc{logits_dev, nullptr, nullptr, 0, 0, 0, 0}), (const float *)e->d_stats, value_dev);
   HIPCHK(e, hipGetLastError());
   mark(e, 4);
   e->stats.launches_expand++;
@@ -561,7 +561,8 @@ int fpc_search_run(fpc_engine *e, int sims) {
     mark(e, 1);
     e->nn.mark_fn = [](void *ctx, int tag) { mark((fpc_engine *)ctx, tag); };
     e->nn.mark_ctx = e;
-    int r = e->policy_mode == FPC_POLICY_LEGAL ? e->nn.forward_legal(e->G, e->t, &e->err) : e->nn.forward(e->G, &e->err);
+    const bool dense = getenv("FPC_DENSE_LOGITS") != nullptr;    // developer knob (A/B): the dense [G][A] logits matrix is written as well
+    int r = e->policy_mode == FPC_POLICY_LEGAL ? e->nn.forward_legal(e->G, e->t, &e->err) : e->nn.forward(e->G, dense, &e->err);
     e->nn.mark_fn = nullptr;
     if (r) return r;
     mark(e, 3);
@@ -574,10 +575,10 @@ int fpc_search_run(fpc_engine *e, int sims) {
         FPC_LAUNCH(k_expand_legal, e->G, 64, e->stream, e->dc, e->t, e->G, (const float *)e->nn.legal_logits(), (const float *)e->nn.value());
     } else {
       if (fuse)
-        FPC_LAUNCH(k_expand_select, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (const float *)e->nn.logits(), (const float *)e->nn.stats(),
+        FPC_LAUNCH(k_expand_select, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, e->nn.logit_src(dense), (const float *)e->nn.stats(),
                    (const float *)e->nn.value(), e->Cpuct, (const double *)e->d_logtab);
       else
-        FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (const float *)e->nn.logits(), (const float *)e->nn.stats(),
+        FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, e->nn.logit_src(dense), (const float *)e->nn.stats(),
                    (const float *)e->nn.value());
     }
     if (fuse) swap_leaf_arrays(e);

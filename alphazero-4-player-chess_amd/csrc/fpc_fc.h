@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(256) k_fc_reduce(const float *part, const floa
       const float4 p = *reinterpret_cast<const float4 *>(part + ((long)(base + k) * Mtot + m) * 256 + (q & 63) * 4);
       v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
     }
-    *reinterpret_cast<float4 *>(logits + (long)m * A + q * 4) = v;
+    if (logits) *reinterpret_cast<float4 *>(logits + (long)m * A + q * 4) = v;     // null: the fused search keeps only the records
   }
   softmax_chunk_stats(v, valid, red, stats + ((long)m * SM_MAXCH + blockIdx.x) * SM_REC);
 }

@@ -775,7 +775,7 @@ struct NN {
       if (fc_layout == 1) hipLaunchKernelGGL((k_fc16<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), FC_LDS, stream, f);
       else hipLaunchKernelGGL((k_fc<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), FC_LDS, stream, f);
       hipLaunchKernelGGL(k_fc_reduce, dim3((dc.A / 4 + 255) / 256, n), dim3(256), 0, stream, (const float *)fc_part, (const float *)fcb,
-                         fc_G1, FC_SPLITK, fc_s2, Gpad, dc.A, n, logits_out, d_stats);
+                         fc_G1, FC_SPLITK, fc_s2, Gpad, dc.A, n, skip_dense ? (float *)nullptr : logits_out, d_stats);
       const hipError_t le = hipGetLastError();
       if (le != hipSuccess) { *err = std::string("k_fc launch failed: ") + hipGetErrorString(le); return FPC_ENODEVICE; }
     }
@@ -785,8 +785,19 @@ struct NN {
     return 0;
   }
 
-  int forward(int n, std::string *err) {
-    return dtype ? forward_t<1>(n, d_logits, d_value, err) : forward_t<0>(n, d_logits, d_value, err);
+  // dense_logits false (the fused search): k_fc_reduce leaves only the softmax records; the expansion adds up the
+  // split-K slabs at the leaf's legal moves itself (logit_src(), fpc_tree_kernels.h: LogitSrc)
+  bool skip_dense = false;
+  int forward(int n, bool dense_logits, std::string *err) {
+    skip_dense = !dense_logits;
+    const int rc = dtype ? forward_t<1>(n, d_logits, d_value, err) : forward_t<0>(n, d_logits, d_value, err);
+    skip_dense = false;
+    return rc;
+  }
+  static_assert(2 * FC_SPLITK <= LOGIT_MAX_SLABS, "logit_at() requests at most LOGIT_MAX_SLABS slabs per column");
+  LogitSrc logit_src(bool dense) const {
+    if (dense) return LogitSrc{d_logits, nullptr, nullptr, 0, 0, 0, 0};
+    return LogitSrc{nullptr, fc_part, fcb, fc_G1, FC_SPLITK, fc_s2, Gpad};
   }
   // ---- legal-only policy head --------------------------------------------------------------
   // one-time: row-major copy of the policy weights + the legal-logit buffer

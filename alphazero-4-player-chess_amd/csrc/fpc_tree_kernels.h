@@ -1499,11 +1499,35 @@ __global__ void __launch_bounds__(SM_THREADS) k_softmax_partials(const float *lo
 // the legal mass is a sequential ascending f32 sum.  The row itself is only touched at the legal moves.
 // ================================================================================================
 constexpr int EXPAND_THREADS = 64;
-__device__ inline void expand_game(WaveLds &s, const DevCfg &c, const Tree &t, int G, int g, const float *logits, const float *stats,
+// Where a leaf's logits come from.  `dense` != null: a [G][A] f32 matrix (external evaluators; fpc_nn_forward).
+// Else: the policy Linear's split-K partial sums as k_fc16 left them -- `part` [slab][Mtot][256] f32 and the bias --
+// which the fused search never combines into a dense matrix: the softmax records come from k_fc_reduce, and the
+// expansion adds up the slabs of a column itself at the leaf's ~40 legal moves, in k_fc_reduce's order
+// (bias, then the group's slabs ascending: the same f32 additions, the same bits).
+constexpr int LOGIT_MAX_SLABS = 8;
+struct LogitSrc {
+  const float *dense;
+  const float *part, *bias;
+  int G1, s1, s2, Mtot;      // column groups [0, G1) own s1 slabs each, the rest s2 (plan_fc)
+};
+__device__ __forceinline__ float logit_at(const LogitSrc &L, int g, int A, int idx) {
+  if (L.dense) return L.dense[(size_t)g * A + idx];
+  const int j = idx >> 8, col = idx & 255;                         // column group of 256 (fpc_fc.h)
+  const int base = j < L.G1 ? j * L.s1 : L.G1 * L.s1 + (j - L.G1) * L.s2, cnt = j < L.G1 ? L.s1 : L.s2;
+  // all of a column's slabs are requested before the first is added (one round trip, not `cnt`): a group has at most
+  // LOGIT_MAX_SLABS = 2 * FC_SPLITK of them (plan_fc)
+  float p[LOGIT_MAX_SLABS];
+#pragma unroll
+  for (int k = 0; k < LOGIT_MAX_SLABS; ++k) p[k] = k < cnt ? L.part[((size_t)(base + k) * L.Mtot + g) * 256 + col] : 0.f;
+  float v = L.bias[idx];
+#pragma unroll
+  for (int k = 0; k < LOGIT_MAX_SLABS; ++k) v = k < cnt ? v + p[k] : v;
+  return v;
+}
+__device__ inline void expand_game(WaveLds &s, const DevCfg &c, const Tree &t, int G, int g, const LogitSrc &logits, const float *stats,
                                    const float *value) {
   const int lane = lane_id();
   const size_t nb = (size_t)g * t.node_cap;
-  const float *lg = logits + (size_t)g * c.A;
   const int nchunks = (c.A / 4 + SM_THREADS - 1) / SM_THREADS;     // A = (8R+8)*R*R is a multiple of 4 for even R
   const float *st = stats + (size_t)g * SM_MAXCH * SM_REC;
   const uint16_t *legal = t.legal + (size_t)g * FPC_MAX_MOVES;
@@ -1540,7 +1564,7 @@ __device__ inline void expand_game(WaveLds &s, const DevCfg &c, const Tree &t, i
     const int fl = j < 64 ? fl0 : (int)legal[j];
     const int plane = fl / c.RR, pos = fl % c.RR;
     const int src = plane * c.RR + rot90_src(c.R, -turn0, pos / c.R, pos % c.R);
-    s.pri[j] = fpc_expf(lg[src] - m) * inv;
+    s.pri[j] = fpc_expf(logit_at(logits, g, c.A, src) - m) * inv;
     s.lsorted[j] = (uint16_t)fl;
   }
   __syncthreads();
@@ -1548,7 +1572,7 @@ __device__ inline void expand_game(WaveLds &s, const DevCfg &c, const Tree &t, i
   expand_finish(s, t, g, nb, n, nl, nan, pre);
 }
 
-__global__ void __launch_bounds__(EXPAND_THREADS) k_expand(DevCfg c, Tree t, int G, const float *logits, const float *stats, const float *value) {
+__global__ void __launch_bounds__(EXPAND_THREADS) k_expand(DevCfg c, Tree t, int G, LogitSrc logits, const float *stats, const float *value) {
   __shared__ WaveLds s;
   const int g = blockIdx.x;
   if (g >= G) return;
@@ -1559,7 +1583,7 @@ __global__ void __launch_bounds__(EXPAND_THREADS) k_expand(DevCfg c, Tree t, int
 // dependent-kernel gap less per step).  Other blocks may still be expanding step s when this block's
 // selection publishes its leaf, and strict mode reads the turn of the batch's FIRST live leaf across games
 // (Q6), so the selection writes the _nx leaf arrays; the host swaps them in after the launch.
-__global__ void __launch_bounds__(EXPAND_THREADS) k_expand_select(DevCfg c, Tree t, int G, const float *logits, const float *stats,
+__global__ void __launch_bounds__(EXPAND_THREADS) k_expand_select(DevCfg c, Tree t, int G, LogitSrc logits, const float *stats,
                                                                   const float *value, double Cpuct, const double *logtab) {
   __shared__ WaveLds s;
   const int g = blockIdx.x;

@@ -458,7 +458,10 @@ def main():
     ach_tower = flops_tower / (tower_ms * 1e-3) / 1e12 if tower_ms > 0 else 0.0
     ach_fc = flops_fc / (fc_ms * 1e-3) / 1e12 if fc_ms > 0 else 0.0
     Np, Kp = (A + 255) // 256 * 256, (A + 511) // 512 * 512
-    fc_bytes = 2.0 * Np * Kp + 2.0 * G * Kp + 4.0 * G * A
+    # algorithmic bytes of the policy Linear inside the fused search: the 16-bit weight matrix read once + X read once.
+    # (The dense f32 logits matrix -- 4 G A bytes -- is no longer written there: k_fc_reduce leaves the softmax records,
+    # the expansion reads the split-K slabs at the legal moves.  FPC_DENSE_LOGITS=1 brings the write back.)
+    fc_bytes = 2.0 * Np * Kp + 2.0 * G * Kp + (4.0 * G * A if os.environ.get("FPC_DENSE_LOGITS") else 0.0)
     pmc = {}
     try:     # HBM bytes per launch measured with rocprofv3 --pmc (tools/pmc_nn.sh), committed under profiles/
         pmc = json.load(open(os.path.join(HERE, "profiles", "pmc_summary.json")))
@@ -496,7 +499,7 @@ def main():
                      "kernel": tower_desc,
                      "flops_per_launch": flops_tower, "ms_per_launch": tower_ms},
         # the policy Linear at M = 256: 255 FLOP per weight byte, below the 312 FLOP/B ridge -> HBM-bound.
-        # algorithmic bytes = the 16-bit weight matrix read once + X read once + f32 logits written once
+        # algorithmic bytes = the 16-bit weight matrix read once + X read once (fc_bytes above)
         "roofline_policy_linear": {"bound": "hbm", "achieved": fc_bytes / (fc_ms * 1e-3) / 1e9 if fc_ms > 0 else 0.0, "peak": PEAK_HBM_GBS,
                                    "unit": "GB/s", "frac": (fc_bytes / (fc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if fc_ms > 0 else 0.0,
                                    "traffic": pmc_traffic(fc_kernels, shape_key),

@@ -37,5 +37,7 @@ bash tools/pmc_fc_mem.sh > gpurun_out/$TAG/pmc_fc_mem.log 2>&1; tail -12 gpurun_
 for p in a b c d e f; do cp gpurun_out/pmcm_$p/*/*counter_collection.csv gpurun_out/$TAG/pmcm_$p.csv 2>/dev/null; done
 bash tools/power_probe.sh --no-alt-dtype > gpurun_out/$TAG/power_probe.log 2>&1; cp gpurun_out/power_samples.txt gpurun_out/$TAG/power_samples.txt; tail -3 gpurun_out/$TAG/power_probe.log | cut -c1-300
 python3 bench.py > gpurun_out/$TAG/default_run.json 2> gpurun_out/$TAG/default_run.err; cut -c1-200 gpurun_out/$TAG/default_run.json
+# the N = 2 launcher path on the one GPU of this box (gloo): rank pinning, host_ms_per_ply, ranks_seen
+python3 bench.py --gpus 2 --rehearse-one-gpu --backend gloo --steps 3 --warmup 1 --no-cpu-baseline --no-alt-dtype --no-alt-policy-head --no-dropin 2> gpurun_out/$TAG/bench_2rank_rehearsal.err | grep "^{" > gpurun_out/$TAG/bench_2rank_rehearsal.json; cut -c1-200 gpurun_out/$TAG/bench_2rank_rehearsal.json   # (gloo prints a connection banner on stdout)
 
 fi

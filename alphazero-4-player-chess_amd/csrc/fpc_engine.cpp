@@ -1019,7 +1019,7 @@ const char *fpc_nn_kernel(fpc_engine *e) {
 }
 void *fpc_stream(fpc_engine *e) { return e ? (void *)e->stream : nullptr; }
 
-#if defined(FPC_TREE_STAMPS) && !defined(FPC_EMUL)
+#ifdef FPC_TREE_STAMPS
 // diagnostic builds only (tools/tree_stamps.py): the s_memtime stamps the tree kernels left for game FPC_TREE_STAMPS
 int fpc_debug_tree_stamps(unsigned long long *out32) {
   return hipMemcpyFromSymbol(out32, HIP_SYMBOL(fpc::g_tree_stamps), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : FPC_ENODEVICE;

@@ -443,7 +443,7 @@ struct NN {
   int tower_waves = getenv("FPC_TOWER_WAVES") ? atoi(getenv("FPC_TOWER_WAVES")) : 8;   // developer knob (A/B): 4 = one wave per SIMD
   bool use_tower256 = false;         // hidden == 256 megakernel: k_towerw<256> (any board size) ...
   bool tower256_v1 = false;          // ... or, FPC_TOWER256_V1=1 on the 14x14 board, round 2's k_tower256
-  bool use_towerw = false;           // k_towerw runs the tower (hidden 256 by default; hidden 128 behind FPC_TOWERW=1)
+  bool use_towerw = false;           // k_towerw runs the tower (hidden 256; hidden 128 on every board but 14x14)
   void (*mark_fn)(void *, int) = nullptr;   // stage-timing hook of the engine (tag 2 = policy Linear starts)
   void *mark_ctx = nullptr;
   float vb = 0.f;
@@ -577,22 +577,27 @@ struct NN {
     // Which megakernel runs the tower (one launch, activations LDS-resident; everything else: k_conv3x3 per layer):
     //   hidden 256: k_towerw (two waves per SIMD, weights L2 -> registers; any board size).  Developer knob for same-box
     //               A/Bs: FPC_TOWER256_V1=1 = round 2's k_tower256 (one wave per SIMD, LDS weight ring; 14x14 only).
-    //   hidden 128: k_tower (LDS-DMA weight ring, loader / staggered wave roles).  Developer knob FPC_TOWERW=1 = k_towerw.
+    //   hidden 128: 14x14: k_tower (LDS-DMA weight ring, loader / staggered wave roles; its grid rows ARE the 16-position row
+    //               tiles there: 0.257 ms per 256 leaves against k_towerw's 0.274); every other board size: k_towerw, whose
+    //               compact image computes ceil(R^2 / 16) row tiles where k_tower's bordered grid needs 6 / 10 / 14
+    //               (8x8: 0.122 against 0.147 ms, 10x10: 0.171 / 0.208, 13x13: 0.242 / 0.285).  Developer knob
+    //               FPC_TOWERW=0 / 1 forces k_tower / k_towerw.
     if (F == 256 && !no_tower) {
       use_tower256 = true;
       tower256_v1 = knob("FPC_TOWER256_V1", 0) != 0 && dc.R == 14;
       use_towerw = !tower256_v1;
     } else if (F == 128 && !no_tower) {
-      use_towerw = knob("FPC_TOWERW", 0) != 0;
+      const int kw = knob("FPC_TOWERW", -1);          // -1: by board size
+      use_towerw = kw < 0 ? dc.R != 14 : kw != 0;
       use_tower = !use_towerw;
     }
     const int layers = 2 * nblocks + 2;
     if (use_towerw) {
       // weights in MFMA fragment order [layer][tap][k-step of 32][cout tile of 16][lane][8] (fpc_towerw.h); one slab =
-      // one k-step of one tap = F * 64 bytes; one slab of padding behind the last layer (the prefetch runs one k-step
-      // ahead without a branch); head convolutions zero-padded to F output channels
+      // one k-step of one tap = F * 64 bytes; TWW_PAD_SLABS slabs of padding behind the last layer (the prefetch runs up
+      // to three k-steps ahead without a branch); head convolutions zero-padded to F output channels
       const int slab = tww_slab(F), ksn = F / 32, tiles = F / 16;
-      if ((rc = dmalloc(&towerW, ((size_t)layers * 9 * ksn + 1) * slab, err)) || (rc = dmalloc(&stemW, (size_t)9 * slab, err)) ||
+      if ((rc = dmalloc(&towerW, ((size_t)layers * 9 * ksn + TWW_PAD_SLABS) * slab, err)) || (rc = dmalloc(&stemW, (size_t)9 * slab, err)) ||
           (rc = dmalloc(&towerB, (size_t)layers * 256, err))) return rc;
       auto prep = [&](const ConvW &cw, int layer) {
         hipLaunchKernelGGL(k_towerw_prep, dim3((9 * ksn * tiles * 64 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)cw.w,
@@ -685,7 +690,7 @@ struct NN {
       t.in16 = in16 + (size_t)guard * 32; t.Wstem = stemW; t.bstem = stem.b; t.Wt = towerW; t.bt = towerB;
       t.xfc = xfc; t.vw = vw; t.value = value_out; t.vb = vb;
       t.L = 2 * nblocks; t.P = P; t.R = dc.R; t.PP = PP; t.NR = PP - P; t.T0 = (P + 1) / 16; t.n_games = n; t.Kp = Kp; t.A_ch = dc.A_ch; t.rules = dc.rules;
-#ifdef TW_STAMPS
+#if defined(TW_STAMPS) || defined(TWW_STAMPS)
       static unsigned long long *d_stamps = nullptr;
       if (!d_stamps) { (void)hipMalloc(&d_stamps, 2 * 8 * 16 * 8); }
       (void)hipMemsetAsync(d_stamps, 0, 2 * 8 * 16 * 8, stream);
@@ -708,18 +713,21 @@ struct NN {
       if (use_towerw) {
         bool &aw = attr_towerw[DT];
         if (!aw) {
-#define FPC_TWW_ATTR(F_, MT_, FAST_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_towerw<DT, F_, MT_, FAST_>), hipFuncAttributeMaxDynamicSharedMemorySize, tww_lds(F_))
-          FPC_TWW_ATTR(256, 3, false); FPC_TWW_ATTR(256, 5, false); FPC_TWW_ATTR(256, 7, false); FPC_TWW_ATTR(256, 7, true);
-          FPC_TWW_ATTR(128, 3, false); FPC_TWW_ATTR(128, 5, false); FPC_TWW_ATTR(128, 7, false); FPC_TWW_ATTR(128, 7, true);
+#define FPC_TWW_ATTR(F_, MT_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_towerw<DT, F_, MT_>), hipFuncAttributeMaxDynamicSharedMemorySize, tww_lds(F_))
+#define FPC_TWW_ATTRS(F_) FPC_TWW_ATTR(F_, 2); FPC_TWW_ATTR(F_, 3); FPC_TWW_ATTR(F_, 4); FPC_TWW_ATTR(F_, 5); FPC_TWW_ATTR(F_, 6); FPC_TWW_ATTR(F_, 7)
+          FPC_TWW_ATTRS(256); FPC_TWW_ATTRS(128);
+#undef FPC_TWW_ATTRS
 #undef FPC_TWW_ATTR
           aw = true;
         }
-#define FPC_TWW_GO(F_, MT_, FAST_) hipLaunchKernelGGL((k_towerw<DT, F_, MT_, FAST_>), dim3(n), dim3(TWW_THREADS), tww_lds(F_), stream, t)
-        if (F == 256) {
-          if (mt == 3) FPC_TWW_GO(256, 3, false); else if (mt == 5) FPC_TWW_GO(256, 5, false); else if (P != 16) FPC_TWW_GO(256, 7, false); else FPC_TWW_GO(256, 7, true);
-        } else {
-          if (mt == 3) FPC_TWW_GO(128, 3, false); else if (mt == 5) FPC_TWW_GO(128, 5, false); else if (P != 16) FPC_TWW_GO(128, 7, false); else FPC_TWW_GO(128, 7, true);
-        }
+        // row tiles of 16 SQUARES for the first wave row (compact image): 8x8 -> 2, 9 -> 3, 10, 11 -> 4, 12 -> 5, 13 -> 6, 14 -> 7
+        const int mtw = tww_mt(dc.R);
+        if (mtw < 2 || mtw > 7) { *err = "k_towerw: board size outside 8..14"; return FPC_EINVAL; }
+#define FPC_TWW_GO(F_, MT_) hipLaunchKernelGGL((k_towerw<DT, F_, MT_>), dim3(n), dim3(TWW_THREADS), tww_lds(F_), stream, t)
+#define FPC_TWW_GOS(F_) switch (mtw) { case 2: FPC_TWW_GO(F_, 2); break; case 3: FPC_TWW_GO(F_, 3); break; case 4: FPC_TWW_GO(F_, 4); break; \
+                                       case 5: FPC_TWW_GO(F_, 5); break; case 6: FPC_TWW_GO(F_, 6); break; default: FPC_TWW_GO(F_, 7); break; }
+        if (F == 256) { FPC_TWW_GOS(256) } else { FPC_TWW_GOS(128) }
+#undef FPC_TWW_GOS
 #undef FPC_TWW_GO
       } else if (tower256_v1) {
         bool &a256 = attr_tower256[DT];
@@ -736,7 +744,7 @@ struct NN {
       else hipLaunchKernelGGL((k_tower<DT, 7, true, 4>), dim3(n), dim3(256), TW_LDS, stream, t);
       const hipError_t le = hipGetLastError();
       if (le != hipSuccess) { *err = std::string("k_tower launch failed: ") + hipGetErrorString(le); return FPC_ENODEVICE; }
-#ifdef TW_STAMPS
+#if defined(TW_STAMPS) || defined(TWW_STAMPS)
       if (getenv("FPC_TW_STAMPS_FILE")) {     // diagnostic build: dump the stamps of this launch
         unsigned long long h[2 * 8 * 16];
         (void)hipStreamSynchronize(stream);

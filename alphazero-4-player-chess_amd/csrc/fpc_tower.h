@@ -84,6 +84,7 @@ constexpr int TW_BIAS = 0;                       // [2][256] f32, filled by LDS-
 constexpr int TW_DUMMY = 2048;                   // 512 B: where non-interior lanes send their epilogue writes
 constexpr int TW_VRED = 2560;                    // [4] f32 value-head partials
 constexpr int TW_BOARD = 2624;                   // the game's leaf board (288 B)
+constexpr int TW_PACE = 2944;                    // k_towerw: [8] k-step counters, one per wave (pacing of the two waves of a SIMD)
 constexpr int TW_IMG0 = 4096;
 constexpr int TW_IMG = 61440;                    // 240 rows x 256 B (14x14: 15 of the 16 grid rows)
 constexpr int TW_TAP = 32768;                    // [128 cout][128 cin] x 2 B

@@ -9,10 +9,10 @@
 // (60-185 cycles of issue port each) 72 times per layer, with nothing to run in their shadow -- ~2 000 cycles per
 // k-step for 896 cycles of matrix pipe.  Here:
 //   * 8 waves, wave (wm, wn) = up to MT row tiles of 16 SQUARES x CT = F/64 column tiles of 16 output channels.
-//     At F = 256, 14x14: 112 accumulator registers + the residual of the same outputs packed (56) + the double-buffered
-//     weight fragments (32) + the image fragments, single-buffered and reloaded in place (28) = 228 of the 256 a wave of
-//     a two-waves-per-SIMD kernel may hold (hipcc parks part of the residual in scratch between two epilogues,
-//     nothing inside a layer's k-steps).
+//     At F = 256, 14x14: 112 accumulator registers + the double-buffered weight fragments (32) + a ring of four image
+//     fragments (16) + seven row offsets, of the 256 a wave of a two-waves-per-SIMD kernel may hold.  The residual is
+//     NOT among them at F = 256 (RESIN below): carried in registers across a residual block (56 more) it ended up parked
+//     in scratch by hipcc, 0.6 GB written per launch.
 //   * COMPACT image: image row 16 + p is square p of the board (no border columns); a tap whose column shift leaves
 //     the board reads a zero row instead (lane masks built on the scalar unit).  ceil(R^2 / 16) row tiles per layer
 //     instead of one per row of the bordered (R + 2)^2 grid: 13 for 14 at 14x14, 4 for 6 at 8x8, 7 for 10 at 10x10.
@@ -28,9 +28,11 @@
 //     (the matrix pipe otherwise serves the older wave first and the younger one runs the end of every layer alone).
 //   * two barriers per layer remain: in front of the layer's last k-step (every wave has read its last image
 //     fragments: the epilogues may rewrite the image in place) and behind the epilogues.
-//   * every output element sees the same MFMAs on the same operands in the same order as in k_tower256 / k_tower:
-//     logits are BIT-IDENTICAL to those kernels'; the value head sums the same terms in another order, the compact
-//     image dealing the squares to other lanes (tests/test_nn_gpu.py).
+//   * every convolution runs the same MFMAs on the same operands in the same order as in k_tower256 / k_tower.  At
+//     F = 128 the logits are BIT-IDENTICAL to k_tower's (the value head sums the same terms in another order, the compact
+//     image dealing the squares to other lanes).  At F = 256 the residual enters conv2's accumulators in front of its
+//     MFMAs instead of behind them: the same terms in another order, outputs within 2e-4 (fp16) of k_tower256's
+//     (tests/test_nn_gpu.py); what counts is the 1e-3 against the reference's fp32 network, unchanged.
 //   * LDS: 4 KiB front strip + 240 image rows x 2F bytes = 124 KiB (F = 256, one workgroup per CU) / 64 KiB (F = 128,
 //     two); hidden = 256 runs as ONE launch at every board size, incl. the reference's shipped ResNet(15, 256) on its
 //     8x8 board (alphazero.py:288); hidden = 128 runs here on every board but 14x14 (k_tower's home: fpc_nn.h).
@@ -41,7 +43,9 @@
 // an EXEC mask: 1.7 k; pacing: 75 k -> 71 k.  An s_load prefetch of the stream three k-steps ahead through the scalar
 // cache bought nothing (the 32 workgroups of an XCD walk the stream together; a slab's first touch is not what a
 // k-step waits for), splitting the row tiles 7 + 6 costs nothing against 7 + 7.
-// Measured (same box, stage timers of bench.py): ResNet(20,256) 14x14, 256 leaves: 1.84 ms per launch against 1.94 for
+// Then (same day): the image fragments as a ring of four (RING: 12 registers) 1.845 -> 1.794 ms, and the residual out
+// of the registers altogether (RESIN) 1.772 -> 1.684 ms, no scratch access left inside a residual block.
+// Measured (same box, stage timers of bench.py): ResNet(20,256) 14x14, 256 leaves: 1.68 ms per launch against 1.94 for
 // round 4's first (bordered) form and k_tower256's 2.74; ResNet(15,256) 8x8, 100 leaves: 0.56 ms against 0.62;
 // ResNet(10,128) 8x8 / 10x10 / 13x13: 0.122 / 0.171 / 0.242 ms against k_tower's 0.147 / 0.208 / 0.285.
 #pragma once
@@ -70,12 +74,18 @@ __host__ __device__ constexpr int tww_lds(int F) { return TWW_IMG0 + TWW_ROWS * 
 __host__ __device__ constexpr int tww_slab(int F) { return F * 64; }             // one 32-deep k-step of one tap: [F cout][32 cin] x 2 B
 // Depth of the weight ring in registers: k-step k reads buffer k mod PD while slab k + PD - 1 is on its way from L2.
 // Two buffers (one k-step of cover: its own MFMAs and its partner's) are all a wave of the full-size kernel
-// (F = 256, MT >= 4) has registers for, and enough there: 2 x 28 MFMAs outlast an L2 round trip.  With few row tiles
+// (F = 256, MT >= 5) has registers for, and enough there: 2 x 28 MFMAs outlast an L2 round trip.  With few row tiles
 // (8x8: 2 x 8 MFMAs per k-step) they do not, and the registers are free: four buffers.
+#ifndef FPC_TWW_RESIN
+#define FPC_TWW_RESIN 1
+#endif
+#ifndef FPC_TWW_RING
+#define FPC_TWW_RING 1
+#endif
 #ifndef FPC_TWW_PD
 #define FPC_TWW_PD 0
 #endif
-__host__ __device__ constexpr int tww_depth(int F, int MT) { return FPC_TWW_PD ? FPC_TWW_PD : (F == 128 || MT <= 3) ? 4 : 2; }
+__host__ __device__ constexpr int tww_depth(int F, int MT) { return FPC_TWW_PD ? FPC_TWW_PD : (F == 128 || MT <= 4) ? 4 : 2; }
 constexpr int TWW_PAD_SLABS = 3;                 // slabs the weight stream is padded with behind the last layer (deepest ring - 1)
 // row tiles (16 squares) of a board and the share of the first wave row (the second gets the rest, at most as many)
 __host__ __device__ constexpr int tww_tiles(int R) { return (R * R + 15) / 16; }
@@ -100,6 +110,12 @@ __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
   constexpr int GRP = F * 16;                      // bytes of 8 image rows
   constexpr int SLAB = tww_slab(F);
   constexpr int PD = tww_depth(F, MT);             // weight fragments of PD - 1 k-steps in flight
+  // Image fragments: with few row tiles one register quad per tile, reloaded in place for the next k-step behind its
+  // MFMAs.  With MT >= 5 a RING of four: the row tiles of a layer are numbered through (c = k-step * MT + tile), tile c
+  // sits in quad c mod 4, and behind its MFMAs the quad is reloaded with tile c + 4 -- same k-step, next k-step or next
+  // tap.  Twelve registers less at MT = 7: hipcc parks 35 instead of 59 dwords per lane of the packed residual per
+  // residual block, and nothing at MT = 5.
+  constexpr bool RING = FPC_TWW_RING != 0 && F == 256 && MT >= 5;     // (F = 128 has the registers: measured 1 % slower there)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *const img = smem + TWW_IMG0;
   float *const vred = reinterpret_cast<float *>(smem + TW_VRED);        // [8]
@@ -175,7 +191,14 @@ __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
 
   // Accumulators are never zeroed: the first MFMA of every layer takes the layer's bias as C.
   t_f32x4 acc[MT][CT];
-  t_u32x2 res[MT][CT];           // residual x_l of this lane's outputs, packed 16-bit channel pairs
+  // The residual x_l of this lane's outputs.  F = 128: packed 16-bit channel pairs in registers across the block's two
+  // convolutions, added to conv2's accumulators in its epilogue (k_tower's order of operations: bit-identical logits).
+  // F = 256 (RESIN): the 56 registers that takes are what hipcc parked in scratch (0.6 GB written per launch), so there
+  // the residual never lives in registers across a k-step: conv1's epilogue reads x_l back from the image -- at the very
+  // address it is about to overwrite with conv1's output -- and leaves  bias2 + x_l  in the accumulators, which conv2's
+  // MFMAs then accumulate on: the same terms summed in another order (last-bit differences against k_tower256).
+  constexpr bool RESIN = FPC_TWW_RESIN != 0 && F == 256;
+  t_u32x2 res[RESIN ? 1 : MT][CT];
   // Where a tap's column shift leaves the board the lane reads a ZERO row instead (rows 0 .. 7, the one with its own
   // row's low three bits: same LDS bank as the read it replaces, so the conflict-free pattern survives): one address
   // select in front of the load, nothing behind it.
@@ -232,8 +255,10 @@ __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
   // select of a dummy address: hipcc turns that into MT x CT address registers, parks them in scratch and waits out a
   // scratch load in front of every store)
   unsigned char *const wbase = img + (rbase >> 3) * GRP + (rbase & 7) * 16 + wn * (CT * 256) + (lane >> 5) * 128 + ((lane >> 4) & 1) * 8;
-  auto epilogue = [&](auto res_c) {
-    constexpr int RES = decltype(res_c)::value;       // 0: plain; 1: keep as residual (stem); 2: add the residual, keep
+  // RES: 0: plain; 1: keep as residual (stem); 2: add the residual, keep (1, 2: F = 128 only); 3 (RESIN, conv1 of a
+  // residual block, `layer`): pick x_l up from the image and leave  bias(layer + 1) + x_l  in the accumulators
+  auto epilogue = [&](auto res_c, const int layer = 0) {
+    constexpr int RES = decltype(res_c)::value;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if (mt == MT - 1 && !last_on) break;            // wave-uniform: the waves wm = 1 own one row tile less on some boards
@@ -246,9 +271,28 @@ __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
           v[2] += M16<DT>::lo(res[mt][ct][1]); v[3] += M16<DT>::hi(res[mt][ct][1]);
         }
         pk[ct] = t_u32x2{tw_relu2(M16<DT>::pack2(v[0], v[1])), tw_relu2(M16<DT>::pack2(v[2], v[3]))};
-        if (RES != 0) res[mt][ct] = pk[ct];
+        if (RES == 1 || RES == 2) res[mt][ct] = pk[ct];
       }
-      if (p0 + 16 * mt < RR) {
+      if (RES == 3) {
+        const float *bn = g.bt + (size_t)(layer + 1) * 256 + tileW * 16 + 4 * lq;
+        t_u32x2 x[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) x[ct] = t_u32x2{0u, 0u};
+        if (p0 + 16 * mt < RR) {
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            t_u32x2 *const at = reinterpret_cast<t_u32x2 *>(wbase + mt * (2 * GRP) + ct * 256);
+            x[ct] = *at;                              // x_l, then conv1's output over it (LDS keeps a wave's accesses in order)
+            *at = pk[ct];
+          }
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const t_f32x4 b = *reinterpret_cast<const t_f32x4 *>(bn + ct * 16);
+          acc[mt][ct] = t_f32x4{b[0] + M16<DT>::lo(x[ct][0]), b[1] + M16<DT>::hi(x[ct][0]),
+                                b[2] + M16<DT>::lo(x[ct][1]), b[3] + M16<DT>::hi(x[ct][1])};
+        }
+      } else if (p0 + 16 * mt < RR) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) *reinterpret_cast<t_u32x2 *>(wbase + mt * (2 * GRP) + ct * 256) = pk[ct];
       }
@@ -258,11 +302,11 @@ __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
   const std::integral_constant<int, 0> c0{};
   const std::integral_constant<int, 1> c1{};
   const std::integral_constant<int, 2> c2{};
-  epilogue(c1);                                       // stem: x_0 = relu(conv + b)
+  if constexpr (RESIN) epilogue(c0); else epilogue(c1);   // stem: x_0 = relu(conv + b)
   __syncthreads();                                    // x_0 complete
 
   // ---- 9 taps x KSN k-steps per layer ---------------------------------------------------------------------
-  t_u32x4 fa[PD][CT], fb[MT];
+  t_u32x4 fa[PD][CT], fb[RING ? 4 : MT];
   int gk = 0;                                         // running slab index over all layers
   uint32_t brow[MT];                                  // image byte offset of this lane's row per row tile under the current tap's shift -- or of its zero row
   auto set_tap = [&](int tap) {
@@ -283,7 +327,7 @@ __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
   auto load_b = [&]() {                               // all image fragments of (tap 0, k-step 0), after an epilogue
     set_tap(0);                                       // here, not in front of the epilogue: MT row offsets less to carry through it
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < (RING ? 4 : MT); ++mt)
       if (mt < MT - 1 || last_on) fb[mt] = *reinterpret_cast<const t_u32x4 *>(bptr(mt, 0));
   };
   // One k-step (slab gk, fragments in fa[KS mod PD] / fb): first the loads of slab gk + PD - 1 into the buffer k-step
@@ -294,7 +338,11 @@ __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
   // tap: offset 0; NEXT = 0: the layer's last k-step: no reload -- the epilogue rewrites the image, load_b() follows).
   // The MT-th row tile exists only for the waves with `last_on` (wave-uniform): 13 = 7 + 6 tiles at 14x14.
   // MODE 0: CT column tiles per wave; 1 (value conv): one.  KS: the k-step's index within its tap (reload offset).
-  auto kstep = [&](auto mode_c, auto ks_c, auto bias_c, auto next_c, auto last_c, const t_f32x4 *b4, const int tile0, const int tile_next) {
+  // RING: NEXT = 2 moves the row offsets to tap `tap_next` itself, behind the last read of this tap's rows (the caller
+  // does not); NEXT = 0 carries the layer's barrier, behind the layer's last image read (tile MT - 1 of this k-step,
+  // issued behind tile MT - 5): every fragment this wave still needs is on its way, the epilogues may rewrite the image.
+  auto kstep = [&](auto mode_c, auto ks_c, auto bias_c, auto next_c, auto last_c, const t_f32x4 *b4, const int tile0, const int tile_next,
+                   const int tap_next = 0) {
     constexpr int MODE = decltype(mode_c)::value, KS = decltype(ks_c)::value, B = KS % PD;
     constexpr bool BIAS = decltype(bias_c)::value != 0;
     constexpr int NEXT = decltype(next_c)::value;
@@ -304,16 +352,31 @@ __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+      const int q = RING ? (KS * MT + mt) & 3 : mt;   // the register quad of this tile
       if (mt < MT - 1 || last_on) {
         if (MODE == 1) {
-          acc[mt][0] = M16<DT>::mfma(fa[B][0], fb[mt], BIAS ? b4[0] : acc[mt][0]);
+          acc[mt][0] = M16<DT>::mfma(fa[B][0], fb[q], BIAS ? b4[0] : acc[mt][0]);
         } else {
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct) acc[mt][ct] = M16<DT>::mfma(fa[B][ct], fb[mt], BIAS ? b4[ct] : acc[mt][ct]);
+          for (int ct = 0; ct < CT; ++ct) acc[mt][ct] = M16<DT>::mfma(fa[B][ct], fb[q], BIAS ? b4[ct] : acc[mt][ct]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (NEXT != 0) {
-          fb[mt] = *reinterpret_cast<const t_u32x4 *>(bptr(mt, NEXT == 1 ? KS + 1 : 0));
+        if (!RING && NEXT != 0) {
+          fb[q] = *reinterpret_cast<const t_u32x4 *>(bptr(mt, NEXT == 1 ? KS + 1 : 0));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if constexpr (RING) {                           // tile c + 4 into the quad tile c has just left (also behind a tile this wave skips)
+        const int tm = mt + 4;
+        if (tm < MT) {                                // ... of this k-step
+          if (tm < MT - 1 || last_on) fb[q] = *reinterpret_cast<const t_u32x4 *>(bptr(tm, KS));
+        } else if (NEXT != 0) {                       // ... of the next one
+          if (NEXT == 2 && tm == MT) set_tap(tap_next);
+          fb[q] = *reinterpret_cast<const t_u32x4 *>(bptr(tm - MT, NEXT == 1 ? KS + 1 : 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (NEXT == 0 && mt == MT - 5) {
+          __syncthreads();
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -364,7 +427,7 @@ __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
   // of (tap 0, k-step 0) and the row address / column mask are tap 0's.  `active`: false for the waves that own none of
   // the layer's live output channels (value conv; policy conv at F = 256): they only keep the layer's barrier and fetch
   // what the layer's last k-step leaves behind.
-  auto run_layer = [&](auto mode_c, const bool active, const int layer, const int tile0, const int tile_next) {
+  auto run_layer = [&](auto mode_c, auto pre_c, const bool active, const int layer, const int tile0, const int tile_next) {
     if (!active) {                                    // wave-uniform
       gk += 9 * KSN;
       __syncthreads();                                // the layer's one barrier
@@ -372,28 +435,29 @@ __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
       return;
     }
     constexpr int MODE = decltype(mode_c)::value;
+    constexpr bool PRE = decltype(pre_c)::value != 0;  // the accumulators already hold the layer's bias (+ the residual): epilogue mode 3
     t_f32x4 b4[CT];
-    {
+    if (!PRE) {
       const float *bl = g.bt + (size_t)layer * 256 + tile0 * 16 + 4 * lq;
 #pragma unroll
       for (int ct = 0; ct < (MODE == 1 ? 1 : CT); ++ct) b4[ct] = *reinterpret_cast<const t_f32x4 *>(bl + ct * 16);
     }
     TWW_STAMP(layer, 0);
-    kstep(mode_c, c0, c1, c1, c0, b4, tile0, tile_next);      // (tap 0, k-step 0), C = bias
+    kstep(mode_c, c0, std::integral_constant<int, PRE ? 0 : 1>{}, c1, c0, b4, tile0, tile_next);      // (tap 0, k-step 0), C = bias
 #pragma unroll 1
     for (int tap = 0; tap < 8; ++tap) {
       FPC_TWW_MID_KSTEPS(c0);
-      set_tap(tap + 1);                               // every read of this tap's rows has been issued
+      if constexpr (!RING) set_tap(tap + 1);          // every read of this tap's rows has been issued
       TWW_STAMP(layer, 1 + tap);
       const int seen = pace_exchange();               // issued in front of the next tap's fragment reads: done when the first of them is
-      kstep(mode_c, std::integral_constant<int, KSN - 1>{}, c0, c2, c0, b4, tile0, tile_next);   // reloads (next tap, k-step 0)
+      kstep(mode_c, std::integral_constant<int, KSN - 1>{}, c0, c2, c0, b4, tile0, tile_next, tap + 1);   // reloads (next tap, k-step 0)
       pace_set(seen);
       kstep(mode_c, c0, c0, c1, c0, b4, tile0, tile_next);      // (next tap, k-step 0)
     }
     FPC_TWW_MID_KSTEPS(c1);                           // tap 8: its late k-steps fetch the next layer's first slabs
     __builtin_amdgcn_s_setprio(0);
     TWW_STAMP(layer, 9);
-    __syncthreads();                                  // every wave holds its last image fragments: the epilogues may rewrite the image
+    if constexpr (!RING) __syncthreads();             // every wave holds its last image fragments: the epilogues may rewrite the image
     TWW_STAMP(layer, 10);
     kstep(mode_c, std::integral_constant<int, KSN - 1>{}, c0, c0, c1, b4, tile0, tile_next);   // the layer's last k-step
     TWW_STAMP(layer, 11);
@@ -405,22 +469,22 @@ __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
   const int nblocks = g.L / 2;
 #pragma unroll 1
   for (int blk = 0; blk < nblocks; ++blk) {
-    run_layer(c0, true, 2 * blk, tileW, tileW);                               // conv1 + BN + ReLU
-    epilogue(c0);
+    run_layer(c0, c0, true, 2 * blk, tileW, tileW);                           // conv1 + BN + ReLU
+    if constexpr (RESIN) epilogue(std::integral_constant<int, 3>{}, 2 * blk); else epilogue(c0);
     TWW_STAMP(2 * blk, 12);
     __syncthreads();
     TWW_STAMP(2 * blk, 13);
     load_b();
     TWW_STAMP(2 * blk, 14);
-    run_layer(c0, true, 2 * blk + 1, tileW, blk + 1 == nblocks ? tile16 : tileW);   // conv2 + BN, + x_l, ReLU
-    epilogue(c2);
+    run_layer(c0, std::integral_constant<int, RESIN ? 1 : 0>{}, true, 2 * blk + 1, tileW, blk + 1 == nblocks ? tile16 : tileW);   // conv2 + BN, + x_l, ReLU
+    if constexpr (RESIN) epilogue(c0); else epilogue(c2);
     __syncthreads();
     load_b();
   }
   float vpart = 0.f;
   {
     // value head (net.py:28-35): relu(conv + b)[pos][ch] . vw[pos][ch], ch < 24 (weights, biases and vw zero-padded to 32)
-    run_layer(c1, half_active, g.L, tile16, tileW);
+    run_layer(c1, c0, half_active, g.L, tile16, tileW);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int p = p0 + 16 * mt;
@@ -436,7 +500,7 @@ __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
     load_b();                                         // the value conv leaves the image as it was
   }
   const bool pol_active = F == 128 || half_active;    // policy conv: 128 output rows (120 live)
-  run_layer(c0, pol_active, g.L + 1, tileW, tileW);                           // policy conv + BN + ReLU, 16-bit rows in place
+  run_layer(c0, c0, pol_active, g.L + 1, tileW, tileW);                           // policy conv + BN + ReLU, 16-bit rows in place
   if (pol_active) epilogue(c0);
   __syncthreads();
 

@@ -175,11 +175,15 @@ def test_towerw_and_tower_give_identical_bits_at_hidden_128(R, blocks, monkeypat
 
 
 @pytest.mark.parametrize("dtype", [1, 0], ids=["fp16", "bf16"])
-def test_tower256_forms_give_identical_bits(dtype, monkeypatch):
-    """k_towerw at hidden 256 (round 4: two waves per SIMD, weights straight from L2 into registers, no barrier inside a layer) and
-    k_tower256 (round 2's one wave per SIMD with the 2-slab LDS ring; developer knob FPC_TOWER256_V1=1, 14x14 only) run
-    the same MFMAs on the same operands in the same order for every output element: logits and values must agree BIT FOR
-    BIT -- for network inputs given as planes and for the fused leaf encode (a short search)."""
+def test_tower256_forms_agree(dtype, monkeypatch):
+    """k_towerw at hidden 256 (round 4: two waves per SIMD, weights straight from L2 into registers, compact image) against
+    k_tower256 (round 2's one wave per SIMD with the 2-slab LDS ring; developer knob FPC_TOWER256_V1=1, 14x14 only): the
+    same network on two independent kernels.  Every convolution sees the same MFMAs on the same operands; k_towerw folds
+    the residual into conv2's accumulators BEFORE its MFMAs (bias + x_l + sum) where k_tower256 adds it behind them
+    (bias + sum + x_l), and its compact image deals the squares to other lanes in the value head: the same terms in
+    another order, so the outputs differ by 16-bit roundings that fall the other way -- far inside the 1e-3 both keep to
+    the fp32 network (test_resnet_forward_vs_torch_fp32, fixture tests).  Network inputs given as planes and the fused
+    leaf encode (a short search) both go through."""
     import torch
     import weights
     R, G = 14, 48
@@ -204,14 +208,14 @@ def test_tower256_forms_give_identical_bits(dtype, monkeypatch):
         outs.append((lg.cpu().numpy().copy(), va.cpu().numpy().copy(), res))
         eng.close()
     monkeypatch.delenv("FPC_TOWER256_V1")
-    # logits: the same MFMAs on the same operands in the same order -> the same bits.  Values: k_towerw's compact image
-    # deals the squares to the lanes differently, so the value head's f32 partial sums are added in another order.
-    assert np.array_equal(outs[0][0], outs[1][0])
-    assert np.abs(outs[0][1] - outs[1][1]).max() < 2e-6
+    tol = 2e-4 if dtype else 2e-3          # a handful of fp16 / bf16 roundings falling the other way
+    dl, dv = np.abs(outs[0][0] - outs[1][0]).max(), np.abs(outs[0][1] - outs[1][1]).max()
+    print("k_towerw vs k_tower256, %s: max|dlogit| = %.3e, max|dvalue| = %.3e" % ("fp16" if dtype else "bf16", dl, dv))
+    assert dl < tol and dv < tol
     assert np.abs(outs[0][0]).mean() > 1e-3
-    for k in ("root_n", "n_children", "flat", "visits", "prior"):
+    for k in ("root_n", "n_children", "flat"):        # the same roots, the same legal moves in the same order
         assert np.array_equal(outs[0][2][k], outs[1][2][k]), k
-    assert np.abs(outs[0][2]["w"] - outs[1][2]["w"]).max() < 1e-4
+    assert np.abs(outs[0][2]["prior"] - outs[1][2]["prior"]).max() < tol
 
 
 @pytest.mark.parametrize("R,dtype", [(14, 1), (8, 0)])

@@ -443,6 +443,7 @@ struct NN {
   int tower_waves = getenv("FPC_TOWER_WAVES") ? atoi(getenv("FPC_TOWER_WAVES")) : 8;   // developer knob (A/B): 4 = one wave per SIMD
   bool use_tower256 = false;         // hidden == 256 megakernel: k_towerw<256> (any board size) ...
   bool tower256_v1 = false;          // ... or, FPC_TOWER256_V1=1 on the 14x14 board, round 2's k_tower256
+  int towerw_rows = 1;               // developer knob FPC_TOWERW_ROWS=2: hidden 256 on two wave rows x four (A/B)
   bool use_towerw = false;           // k_towerw runs the tower (hidden 256; hidden 128 on every board but 14x14)
   void (*mark_fn)(void *, int) = nullptr;   // stage-timing hook of the engine (tag 2 = policy Linear starts)
   void *mark_ctx = nullptr;
@@ -586,6 +587,7 @@ struct NN {
       use_tower256 = true;
       tower256_v1 = knob("FPC_TOWER256_V1", 0) != 0 && dc.R == 14;
       use_towerw = !tower256_v1;
+      towerw_rows = knob("FPC_TOWERW_ROWS", 1);
     } else if (F == 128 && !no_tower) {
       const int kw = knob("FPC_TOWERW", -1);          // -1: by board size
       use_towerw = kw < 0 ? dc.R != 14 : kw != 0;
@@ -716,8 +718,10 @@ struct NN {
 #define FPC_TWW_ATTR(F_, MT_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_towerw<DT, F_, MT_>), hipFuncAttributeMaxDynamicSharedMemorySize, tww_lds(F_))
 #define FPC_TWW_ATTRS(F_) FPC_TWW_ATTR(F_, 2); FPC_TWW_ATTR(F_, 3); FPC_TWW_ATTR(F_, 4); FPC_TWW_ATTR(F_, 5); FPC_TWW_ATTR(F_, 6); FPC_TWW_ATTR(F_, 7)
           FPC_TWW_ATTRS(256); FPC_TWW_ATTRS(128);
-#undef FPC_TWW_ATTRS
-#undef FPC_TWW_ATTR
+#define FPC_TWW_ATTR1(F_, MT_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_towerw<DT, F_, MT_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, tww_lds(F_))
+          FPC_TWW_ATTR1(128, 4); FPC_TWW_ATTR1(256, 4); FPC_TWW_ATTR1(256, 6); FPC_TWW_ATTR1(256, 7); FPC_TWW_ATTR1(256, 8);
+          FPC_TWW_ATTR1(256, 9); FPC_TWW_ATTR1(256, 11); FPC_TWW_ATTR1(256, 13);
+#undef FPC_TWW_ATTR1
           aw = true;
         }
         // row tiles of 16 SQUARES for the first wave row (compact image): 8x8 -> 2, 9 -> 3, 10, 11 -> 4, 12 -> 5, 13 -> 6, 14 -> 7
@@ -726,7 +730,20 @@ struct NN {
 #define FPC_TWW_GO(F_, MT_) hipLaunchKernelGGL((k_towerw<DT, F_, MT_>), dim3(n), dim3(TWW_THREADS), tww_lds(F_), stream, t)
 #define FPC_TWW_GOS(F_) switch (mtw) { case 2: FPC_TWW_GO(F_, 2); break; case 3: FPC_TWW_GO(F_, 3); break; case 4: FPC_TWW_GO(F_, 4); break; \
                                        case 5: FPC_TWW_GO(F_, 5); break; case 6: FPC_TWW_GO(F_, 6); break; default: FPC_TWW_GO(F_, 7); break; }
-        if (F == 256) { FPC_TWW_GOS(256) } else { FPC_TWW_GOS(128) }
+        // One wave row (eight waves side by side along the output channels, each over ALL row tiles): hidden 256 at every
+        // board size, hidden 128 at 8x8.  Two wave rows x four: hidden 128 elsewhere.  FPC_TOWERW_ROWS=2 forces the latter.
+        const int tiles = tww_tiles(dc.R);
+        const bool onerow = tiles <= 4 || (F == 256 && towerw_rows != 2);
+#define FPC_TWW_GO1(F_, MT_) hipLaunchKernelGGL((k_towerw<DT, F_, MT_, true>), dim3(n), dim3(TWW_THREADS), tww_lds(F_), stream, t)
+        if (onerow && F == 128) FPC_TWW_GO1(128, 4);
+        else if (onerow) {
+          switch (tiles) {
+            case 4: FPC_TWW_GO1(256, 4); break;   case 6: FPC_TWW_GO1(256, 6); break;   case 7: FPC_TWW_GO1(256, 7); break;
+            case 8: FPC_TWW_GO1(256, 8); break;   case 9: FPC_TWW_GO1(256, 9); break;   case 11: FPC_TWW_GO1(256, 11); break;
+            default: FPC_TWW_GO1(256, 13); break;
+          }
+        } else if (F == 256) { FPC_TWW_GOS(256) } else { FPC_TWW_GOS(128) }
+#undef FPC_TWW_GO1
 #undef FPC_TWW_GOS
 #undef FPC_TWW_GO
       } else if (tower256_v1) {

@@ -73,9 +73,9 @@ constexpr int TWW_ROWS = 240;                    // image rows: 16 zero rows, up
 __host__ __device__ constexpr int tww_lds(int F) { return TWW_IMG0 + TWW_ROWS * F * 2; }
 __host__ __device__ constexpr int tww_slab(int F) { return F * 64; }             // one 32-deep k-step of one tap: [F cout][32 cin] x 2 B
 // Depth of the weight ring in registers: k-step k reads buffer k mod PD while slab k + PD - 1 is on its way from L2.
-// Two buffers (one k-step of cover: its own MFMAs and its partner's) are all a wave of the full-size kernel
-// (F = 256, MT >= 5) has registers for, and enough there: 2 x 28 MFMAs outlast an L2 round trip.  With few row tiles
-// (8x8: 2 x 8 MFMAs per k-step) they do not, and the registers are free: four buffers.
+// Two buffers (one k-step of cover: its own MFMAs and its partner's) are enough where a k-step is long (14x14 at
+// F = 256: 2 x 26 MFMAs outlast an L2 round trip; measured 1.646 ms with two against 1.665 with four); with fewer row
+// tiles they are not, and the registers are free: four buffers.
 #ifndef FPC_TWW_RESIN
 #define FPC_TWW_RESIN 1
 #endif
@@ -85,7 +85,9 @@ __host__ __device__ constexpr int tww_slab(int F) { return F * 64; }            
 #ifndef FPC_TWW_PD
 #define FPC_TWW_PD 0
 #endif
-__host__ __device__ constexpr int tww_depth(int F, int MT) { return FPC_TWW_PD ? FPC_TWW_PD : (F == 128 || MT <= 4) ? 4 : 2; }
+__host__ __device__ constexpr int tww_depth(int F, int MT, bool onerow) {
+  return FPC_TWW_PD ? FPC_TWW_PD : onerow ? (MT >= 12 ? 2 : 4) : (F == 128 || MT <= 4) ? 4 : 2;
+}
 constexpr int TWW_PAD_SLABS = 3;                 // slabs the weight stream is padded with behind the last layer (deepest ring - 1)
 // row tiles (16 squares) of a board and the share of the first wave row (the second gets the rest, at most as many)
 __host__ __device__ constexpr int tww_tiles(int R) { return (R * R + 15) / 16; }
@@ -102,14 +104,18 @@ __host__ __device__ constexpr int tww_mt(int R) { return (tww_tiles(R) + 1) / 2;
 // TowerArgs as for k_tower, with: Wstem = 9 slabs, Wt = (L + 2) * 9 * (F / 32) slabs + one slab of padding, both in
 // fragment order; bt = [L + 2][256]; bstem = [F]; in16 (external input) in k_tower's bordered-grid layout.
 // MT = tww_mt(R): row tiles of the waves wm = 0; the waves wm = 1 own tww_tiles(R) - MT (MT or MT - 1) of them.
-template <int DT, int F, int MT>
+// ONEROW (boards of at most four row tiles: 8x8): all eight waves side by side along the output channels (wave = all MT
+// row tiles x F/128 column tiles) instead of 2 wave rows x 4: with so few row tiles a k-step is bound by the weight
+// fragments it pulls through the CU's L1, and two wave rows pull every fragment twice.
+template <int DT, int F, int MT, bool ONEROW = false>
 __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
   constexpr int NT = TWW_THREADS;
-  constexpr int CT = F / 64;                       // column tiles (16 output channels) per wave: 4 or 2
+  constexpr int WN = ONEROW ? 8 : 4;               // waves along the output channels
+  constexpr int CT = F / 16 / WN;                  // column tiles (16 output channels) per wave: 4 or 2 (ONEROW: 2 or 1)
   constexpr int KSN = F / 32;                      // k-steps per tap: 8 or 4
   constexpr int GRP = F * 16;                      // bytes of 8 image rows
   constexpr int SLAB = tww_slab(F);
-  constexpr int PD = tww_depth(F, MT);             // weight fragments of PD - 1 k-steps in flight
+  constexpr int PD = tww_depth(F, MT, ONEROW);     // weight fragments of PD - 1 k-steps in flight
   // Image fragments: with few row tiles one register quad per tile, reloaded in place for the next k-step behind its
   // MFMAs.  With MT >= 5 a RING of four: the row tiles of a layer are numbered through (c = k-step * MT + tile), tile c
   // sits in quad c mod 4, and behind its MFMAs the quad is reloaded with tile c + 4 -- same k-step, next k-step or next
@@ -122,7 +128,7 @@ __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
   fpc_board *const lboard = reinterpret_cast<fpc_board *>(smem + TW_BOARD);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;             // waves w and w + 4 (wm = 0 / 1 of one wn) share a SIMD: 7 + 6 row tiles each at 14x14
+  const int wm = ONEROW ? 0 : wave >> 2, wn = ONEROW ? wave : wave & 3;   // waves w and w + 4 share a SIMD: 7 + 6 row tiles at 14x14
   const int li = lane & 15, lq = lane >> 4;
   const int game = blockIdx.x;
   const int R = g.R, RR = R * R;
@@ -136,7 +142,7 @@ __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
 
   // ---- per-lane geometry: this lane's square in row tile mt is p0 + 16 mt ------------------------------------
   const int p0 = wm * MT * 16 + li;
-  const bool last_on = wm == 0 || tww_tiles(R) == 2 * MT;   // wave-uniform: does this wave own an MT-th row tile (13 = 7 + 6 at 14x14)
+  const bool last_on = ONEROW || wm == 0 || tww_tiles(R) == 2 * MT;   // wave-uniform: does this wave own an MT-th row tile (13 = 7 + 6 at 14x14)
   // Which lanes of row tile mt sit in board column 0 (a tap with dx = -1 reads off the board there) or R - 1 (dx = +1)?
   // Square p0 + 16 mt = tile_base + li is in column 0 iff li == colk[mt] (mod R), colk[mt] := (-tile_base) mod R, and in
   // column R - 1 iff li == colk[mt] - 1 (mod R): the lane mask of a tap is built on the SCALAR unit from MT wave-uniform
@@ -499,7 +505,7 @@ __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
     }
     load_b();                                         // the value conv leaves the image as it was
   }
-  const bool pol_active = F == 128 || half_active;    // policy conv: 128 output rows (120 live)
+  const bool pol_active = tileW < 8;                  // policy conv: 128 output rows (120 live) = 8 column tiles
   run_layer(c0, c0, pol_active, g.L + 1, tileW, tileW);                           // policy conv + BN + ReLU, 16-bit rows in place
   if (pol_active) epilogue(c0);
   __syncthreads();

@@ -174,6 +174,36 @@ def test_towerw_and_tower_give_identical_bits_at_hidden_128(R, blocks, monkeypat
         assert np.abs(outs[0][0]).mean() > 1e-3
 
 
+@pytest.mark.parametrize("R,blocks", [(14, 3), (8, 3), (10, 2), (13, 2)])
+def test_towerw_wave_tilings_give_identical_logits_at_hidden_256(R, blocks, monkeypatch):
+    """k_towerw<256> on one wave row (eight waves side by side along the output channels, each over all row tiles: the
+    default) against two wave rows x four (developer knob FPC_TOWERW_ROWS=2): every output element sees the same MFMAs
+    on the same operands in the same order -> logits bit for bit; the value head sums its terms in another order."""
+    import torch
+    import weights
+    m = _model(R, blocks, 256, seed=11)
+    G = 40
+    x = (torch.rand(G, 24, R, R, generator=torch.Generator().manual_seed(R)) < 0.1).float().cuda()
+    for dtype in (1, 0):
+        outs = []
+        for rows in ("1", "2"):
+            monkeypatch.setenv("FPC_TOWERW_ROWS", rows)
+            eng = make_engine("gpu", R, INV_OF[R], max_games=G, max_sims=4, nn_dtype=dtype)
+            eng.load_weights(weights.export_weights(m, dtype))
+            assert (eng.L.fpc_nn_kernel(eng.h) or b"").decode() == "k_towerw"
+            lg = torch.empty(G, eng.A, device="cuda")
+            va = torch.empty(G, device="cuda")
+            for _ in range(2):
+                eng.nn_forward(x.data_ptr(), G, lg.data_ptr(), va.data_ptr())
+            torch.cuda.synchronize()
+            outs.append((lg.cpu().numpy().copy(), va.cpu().numpy().copy()))
+            eng.close()
+        monkeypatch.delenv("FPC_TOWERW_ROWS")
+        assert np.array_equal(outs[0][0], outs[1][0]), (R, dtype)
+        assert np.abs(outs[0][1] - outs[1][1]).max() < 2e-6, (R, dtype)
+        assert np.abs(outs[0][0]).mean() > 1e-3
+
+
 @pytest.mark.parametrize("dtype", [1, 0], ids=["fp16", "bf16"])
 def test_tower256_forms_agree(dtype, monkeypatch):
     """k_towerw at hidden 256 (round 4: two waves per SIMD, weights straight from L2 into registers, compact image) against

@@ -1,4 +1,4 @@
-// fpc_towerw.h -- k_towerw<DT, F, MT> (round 4): the residual tower of net.py:6-63 (stem + 2*Nb residual convs +
+// fpc_towerw.h -- k_towerw<DT, F, MT, ONEROW> (round 4): the residual tower of net.py:6-63 (stem + 2*Nb residual convs +
 // both head convs) in ONE launch, one game per workgroup, activations resident in LDS, for hidden F = 128 or 256 and
 // any board of 8..14 squares a side -- on TWO WAVES PER SIMD with the weights going straight from L2 into registers:
 // no weight ring in LDS, no LDS-DMA, no barrier inside a layer.
@@ -8,9 +8,12 @@
 // what stood between two k-steps was: `s_waitcnt vmcnt(0)`, the workgroup barrier and a burst of four LDS-DMA pieces
 // (60-185 cycles of issue port each) 72 times per layer, with nothing to run in their shadow -- ~2 000 cycles per
 // k-step for 896 cycles of matrix pipe.  Here:
-//   * 8 waves, wave (wm, wn) = up to MT row tiles of 16 SQUARES x CT = F/64 column tiles of 16 output channels.
-//     At F = 256, 14x14: 112 accumulator registers + the double-buffered weight fragments (32) + a ring of four image
-//     fragments (16) + seven row offsets, of the 256 a wave of a two-waves-per-SIMD kernel may hold.  The residual is
+//   * 8 waves.  F = 256 (and F = 128 at 8x8): ONE wave row, the waves side by side along the output channels, each over
+//     all MT = ceil(R^2 / 16) row tiles of 16 SQUARES x F/128 column tiles of 16 channels -- at 14x14: 104 accumulator
+//     registers + double-buffered weight fragments (16) + a ring of four image fragments (16) + 13 row offsets, of the
+//     256 a wave of a two-waves-per-SIMD kernel may hold.  F = 128 elsewhere: two wave rows x four, wave (wm, wn) = up to
+//     MT = ceil(tiles / 2) row tiles x 2 column tiles (one wave row would read one image fragment per MFMA there).
+//     Two wave rows pull every weight fragment through the CU's L1 twice: with few row tiles that bounds the k-step.  The residual is
 //     NOT among them at F = 256 (RESIN below): carried in registers across a residual block (56 more) it ended up parked
 //     in scratch by hipcc, 0.6 GB written per launch.
 //   * COMPACT image: image row 16 + p is square p of the board (no border columns); a tap whose column shift leaves
@@ -45,9 +48,10 @@
 // k-step waits for), splitting the row tiles 7 + 6 costs nothing against 7 + 7.
 // Then (same day): the image fragments as a ring of four (RING: 12 registers) 1.845 -> 1.794 ms, and the residual out
 // of the registers altogether (RESIN) 1.772 -> 1.684 ms, no scratch access left inside a residual block.
-// Measured (same box, stage timers of bench.py): ResNet(20,256) 14x14, 256 leaves: 1.68 ms per launch against 1.94 for
-// round 4's first (bordered) form and k_tower256's 2.74; ResNet(15,256) 8x8, 100 leaves: 0.56 ms against 0.62;
-// ResNet(10,128) 8x8 / 10x10 / 13x13: 0.122 / 0.171 / 0.242 ms against k_tower's 0.147 / 0.208 / 0.285.
+// One wave row instead of two: 1.72 -> 1.65 ms, and 0.56 -> 0.36 ms for ResNet(15,256) on the 8x8 board.
+// Measured (same box, stage timers of bench.py): ResNet(20,256) 14x14, 256 leaves: 1.65 ms per launch against 1.94 for
+// round 4's first (bordered) form and k_tower256's 2.74; ResNet(15,256) 8x8, 100 leaves: 0.36 ms against 0.62;
+// ResNet(10,128) 8x8 / 10x10 / 13x13: 0.120 / 0.171 / 0.242 ms against k_tower's 0.147 / 0.208 / 0.285.
 #pragma once
 #include "fpc_tower.h"
 
@@ -55,7 +59,7 @@ namespace fpc {
 
 constexpr int TWW_THREADS = 512;
 constexpr int TWW_IMG0 = 4096;                   // [0, 4096): dummy strip, value partials, leaf board (k_tower's offsets)
-// diagnostic builds (-DTWW_STAMPS=<layer index>; tools/towerw_stamps.py): s_memtime (100 MHz) at 15 points of one conv
+// diagnostic builds (-DTWW_STAMPS=<layer index>; tools/towerw_stamps.py): s_memtime (shader cycles) at 15 points of one conv
 // layer, every wave of blocks 0 and 131, parked in LDS and copied out at the end
 #ifdef TWW_STAMPS
 #define TWW_STAMP(LAYER, I)                                                                                   \

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic build only (hipcc ... -DTWW_STAMPS=<conv layer index, even> -o tools/lib_stamps.so): timeline of one
-conv layer of k_towerw, blocks 0 and 131, every wave -- s_memtime ticks (100 MHz reference clock: x10 ns).
+conv layer of k_towerw, blocks 0 and 131, every wave -- s_memtime ticks (= shader cycles on gfx950, about 2.0 GHz under this load).
     FPC_ENGINE_LIB=$PWD/tools/lib_stamps.so FPC_NN_BLOCKS=20 FPC_NN_HIDDEN=256 python3 tools/towerw_stamps.py"""
 import os, subprocess, sys
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -82,8 +82,8 @@ def _positions(R, n):
                                                        (14, 2, 64, 1, 1e-3), (14, 2, 64, 0, 8e-3),
                                                        (14, 3, 128, 1, 1e-3), (14, 3, 128, 0, 8e-3), (8, 3, 128, 0, 8e-3),
                                                        (8, 2, 256, 1, 1e-3), (10, 2, 128, 1, 1e-3),
-                                                       # hidden 256: k_towerw at every row-tile count (MT 2 .. 7, with and without a short second wave row)
-                                                       (8, 3, 256, 0, 8e-3), (10, 2, 256, 1, 1e-3), (11, 2, 256, 1, 1e-3), (12, 2, 256, 1, 1e-3),
+                                                       # hidden 256: k_towerw on one wave row at every row-tile count (MT = 4, 6, 7, 8, 9, 11, 13)
+                                                       (8, 3, 256, 0, 8e-3), (9, 2, 256, 1, 1e-3), (10, 2, 256, 1, 1e-3), (11, 2, 256, 1, 1e-3), (12, 2, 256, 1, 1e-3),
                                                        (13, 2, 256, 1, 1e-3), (14, 2, 256, 1, 1e-3), (14, 2, 256, 0, 8e-3),
                                                        # sizes without a reference layout (hidden 128 off 14x14: k_towerw, MT 3 / 4 / 5 / 6)
                                                        (9, 2, 128, 1, 1e-3), (11, 2, 128, 1, 1e-3), (12, 2, 128, 1, 1e-3), (13, 2, 128, 1, 1e-3)])
@@ -388,16 +388,19 @@ def test_resnet_forward_more_than_256_rows():
     eng.close()
 
 
-@pytest.mark.parametrize("R,dtype,rules", [(8, 0, 0), (14, 1, 0), (14, 1, 15), (8, 1, 15)])
-def test_fused_search_equals_stepwise(R, dtype, rules):
+@pytest.mark.parametrize("R,dtype,rules,hidden", [(8, 0, 0, 64), (14, 1, 0, 64), (14, 1, 15, 64), (8, 1, 15, 64),
+                                                  # k_towerw's own leaf encode into its compact image: one wave row at
+                                                  # hidden 128 (8x8) and 256, two wave rows at hidden 128 elsewhere
+                                                  (8, 1, 0, 128), (8, 1, 15, 128), (10, 1, 15, 128), (10, 1, 0, 256), (13, 0, 15, 256)])
+def test_fused_search_equals_stepwise(R, dtype, rules, hidden):
     """fpc_search_run (encode->MFMA net->expand, no host round trip) must give exactly the visit
     counts of the step-wise path fed with the same network's outputs -- under the strict rules and
     under the non-strict rule set with root noise (N4: fused encode / decode rotations, plane numbering)."""
     import torch
     import weights
-    m = _model(R, 2, 64, seed=3)
+    m = _model(R, 2, hidden, seed=3)
     G, sims = 12, 48
-    eng = make_engine("gpu", R, gold(R)["INV"], max_games=G, max_sims=sims, nn_dtype=dtype)
+    eng = make_engine("gpu", R, INV_OF[R], max_games=G, max_sims=sims, nn_dtype=dtype)
     eng.load_weights(weights.export_weights(m, dtype))
     eng.set_rules(rules)
     if rules:

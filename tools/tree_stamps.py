@@ -43,5 +43,5 @@ for chunk in (50, 150, sims - 200):
             continue
         print("  %-34s %6d ticks" % (names[i], t[i] - prev))
         prev = t[i]
-    print("  total %d ticks (s_memtime; 100 MHz reference clock => x10 ns)" % (t[13] - t[0]))
+    print("  total %d ticks (s_memtime = shader cycles on gfx950: about 0.5 ns each under this load)" % (t[13] - t[0]))
 eng.search_results()

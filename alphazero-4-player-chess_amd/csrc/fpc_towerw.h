@@ -99,18 +99,20 @@ __host__ __device__ constexpr int tww_mt(int R) { return (tww_tiles(R) + 1) / 2;
 
 // COMPACT image (round 4): image row 16 + p holds square p = R * i + j of the board -- no border columns, 16 zero rows
 // in front of square 0 and zero rows behind the last one.  A 3x3 tap (dy, dx) is then the row shift R * dy + dx for every
-// square EXCEPT where j + dx leaves the board (the shifted row is the neighbouring board row's far end): those lanes'
-// image fragments are zeroed behind the load (one v_cndmask per register, dx != 0 taps only; the conv's zero padding
-// in the row direction is the zero rows).  Against the bordered (R + 2)^2 grid of k_tower / k_tower256 this computes
+// square EXCEPT where j + dx leaves the board (the shifted row is the neighbouring board row's far end): those lanes
+// read one of the zero rows instead (an address select per row tile and tap, `set_tap`; the conv's zero padding in the
+// row direction is the zero rows).  Against the bordered (R + 2)^2 grid of k_tower / k_tower256 this computes
 // ceil(R^2 / 16) row tiles instead of one per grid row: 13 instead of 14 at 14x14 (-7 % MFMAs), 4 instead of 6 at 8x8,
 // 7 instead of 10 at 10x10 -- and every tile is 16 CONSECUTIVE image rows at every board size, so the conflict-free
 // fragment reads and the constant tile-to-tile address step hold everywhere (no generic addressing path).
-// TowerArgs as for k_tower, with: Wstem = 9 slabs, Wt = (L + 2) * 9 * (F / 32) slabs + one slab of padding, both in
+// TowerArgs as for k_tower, with: Wstem = 9 slabs, Wt = (L + 2) * 9 * (F / 32) slabs + TWW_PAD_SLABS of padding, both in
 // fragment order; bt = [L + 2][256]; bstem = [F]; in16 (external input) in k_tower's bordered-grid layout.
-// MT = tww_mt(R): row tiles of the waves wm = 0; the waves wm = 1 own tww_tiles(R) - MT (MT or MT - 1) of them.
-// ONEROW (boards of at most four row tiles: 8x8): all eight waves side by side along the output channels (wave = all MT
-// row tiles x F/128 column tiles) instead of 2 wave rows x 4: with so few row tiles a k-step is bound by the weight
-// fragments it pulls through the CU's L1, and two wave rows pull every fragment twice.
+// Two wave rows x four (ONEROW = false; F = 128 off the 8x8 board): MT = tww_mt(R) row tiles for the waves wm = 0, the
+// waves wm = 1 own tww_tiles(R) - MT (MT or MT - 1) of them.
+// ONEROW (F = 256 at every board size, F = 128 at 8x8; MT = tww_tiles(R)): all eight waves side by side along the output
+// channels, wave = all MT row tiles x F/128 column tiles.  Two wave rows pull every weight fragment through the CU's
+// L1 twice, which bounds the k-step when there are few row tiles; at F = 128 with many row tiles one wave row would
+// read one image fragment per MFMA instead (LDS-bound).
 template <int DT, int F, int MT, bool ONEROW = false>
 __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
   constexpr int NT = TWW_THREADS;
@@ -123,8 +125,7 @@ __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
   // Image fragments: with few row tiles one register quad per tile, reloaded in place for the next k-step behind its
   // MFMAs.  With MT >= 5 a RING of four: the row tiles of a layer are numbered through (c = k-step * MT + tile), tile c
   // sits in quad c mod 4, and behind its MFMAs the quad is reloaded with tile c + 4 -- same k-step, next k-step or next
-  // tap.  Twelve registers less at MT = 7: hipcc parks 35 instead of 59 dwords per lane of the packed residual per
-  // residual block, and nothing at MT = 5.
+  // tap.  Twelve registers less at MT = 7 (two wave rows), 36 at MT = 13 (one).
   constexpr bool RING = FPC_TWW_RING != 0 && F == 256 && MT >= 5;     // (F = 128 has the registers: measured 1 % slower there)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *const img = smem + TWW_IMG0;

@@ -80,6 +80,9 @@ __host__ __device__ constexpr int tww_slab(int F) { return F * 64; }            
 // Two buffers (one k-step of cover: its own MFMAs and its partner's) are enough where a k-step is long (14x14 at
 // F = 256: 2 x 26 MFMAs outlast an L2 round trip; measured 1.646 ms with two against 1.665 with four); with fewer row
 // tiles they are not, and the registers are free: four buffers.
+#ifndef FPC_TWW_BUFLOAD
+#define FPC_TWW_BUFLOAD 1
+#endif
 #ifndef FPC_TWW_RESIN
 #define FPC_TWW_RESIN 1
 #endif
@@ -329,11 +332,24 @@ __global__ void __launch_bounds__(TWW_THREADS, 2) k_towerw(TowerArgs g) {
   };
   // ks: k-step within the tap (64 B per k-step along a row; the zero rows are zero at every k)
   auto bptr = [&](int mt, int ks) -> const unsigned char * { return img + brow[mt] + ks * 512; };
+  // The weight stream through a buffer resource: scalar base + scalar byte offset (slab, first tile) + ONE 32-bit lane
+  // offset + an immediate per column tile -- no 64-bit address arithmetic in vector registers, half the address data
+  // per load (`buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen offset:imm`).
+#if FPC_TWW_BUFLOAD
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(g.Wt), 0, 0x7fffffff, 0x00020000);
+#endif
   auto wload = [&](auto buf_c, int slab, int tile0) {  // the wave's CT A fragments of slab `slab`, straight into registers
     constexpr int B = decltype(buf_c)::value;
+#if FPC_TWW_BUFLOAD
+    const int soff = slab * SLAB + tile0 * 1024;      // wave-uniform; the stream is < 2 GiB
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+      fa[B][ct] = __builtin_bit_cast(t_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)wlane + ct * 1024, soff, 0));
+#else
     const unsigned char *wsrc = g.Wt + (size_t)slab * SLAB + tile0 * 1024;      // wave-uniform
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) fa[B][ct] = *reinterpret_cast<const t_u32x4 *>(wsrc + ct * 1024 + wlane);
+#endif
   };
   auto load_b = [&]() {                               // all image fragments of (tap 0, k-step 0), after an epilogue
     set_tap(0);                                       // here, not in front of the epilogue: MT row offsets less to carry through it

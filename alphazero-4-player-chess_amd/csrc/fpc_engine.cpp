@@ -70,7 +70,10 @@ struct fpc_engine {
   void *comm = nullptr;             // ncclComm_t
   int comm_rank = 0, comm_world = 1;
   fpc_tuple *d_gather = nullptr;    // [world][gather_stride]
-  long long *d_gcounts = nullptr;   // [2 * (world + 1)]: all-gathered (count, capacity) pairs; the last pair = this rank's send values
+  long long *d_gcounts = nullptr;   // [3 * world + 4]: all-gathered (count, capacity, epoch) records | this rank's own record | its status word
+  long long comm_epoch = 0;         // exchanges started on this communicator (tags every record and status word)
+  int comm_fault = 0;               // fpc_debug_comm_fault
+  int gcounts_world = 0;
   int gather_stride = 0;
   size_t gather_cap = 0;            // tuples the receive buffer holds (world x padded count)
   std::vector<int> gather_counts;
@@ -229,7 +232,7 @@ void resolve_marks(fpc_engine *e) {
 
 extern "C" {
 
-int fpc_abi_version(void) { return 6; }
+int fpc_abi_version(void) { return 7; }
 
 const char *fpc_last_error(const fpc_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
@@ -515,7 +518,7 @@ int fpc_search_expand_select(fpc_engine *e, const float *logits_dev, const float
   e->sims_issued += 1;
   mark(e, 3);
   launch_partials(e, logits_dev);
-  FPC_LAUNCH(k_expand_select, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (LogitSrc{logits_dev, nullptr, nullptr, 0, 0, 0, 0}),
+  FPC_LAUNCH(k_expand_select, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (LogitSrc{logits_dev, nullptr, nullptr, 0, 0, 0, 0, 256}),
              (const float *)e->d_stats, value_dev, e->Cpuct, (const double *)e->d_logtab);
   HIPCHK(e, hipGetLastError());
   swap_leaf_arrays(e);
@@ -531,7 +534,7 @@ int fpc_search_expand(fpc_engine *e, const float *logits_dev, const float *value
   if (!logits_dev || !value_dev) return fail(e, FPC_EINVAL, "null logits/value");
   mark(e, 3);
   launch_partials(e, logits_dev);
-  FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (LogitSrc{logits_dev, nullptr, nullptr, 0, 0, 0, 0}), (const float *)e->d_stats, value_dev);
+  FPC_LAUNCH(k_expand, e->G, EXPAND_THREADS, e->stream, e->dc, e->t, e->G, (LogitSrc{logits_dev, nullptr, nullptr, 0, 0, 0, 0, 256}), (const float *)e->d_stats, value_dev);
   HIPCHK(e, hipGetLastError());
   mark(e, 4);
   e->stats.launches_expand++;
@@ -762,6 +765,7 @@ struct Rccl {
   typedef int (*destroy_t)(void *);
   typedef const char *(*errstr_t)(int);
   void *h = nullptr;
+  destroy_t abort = nullptr;        // ncclCommAbort (optional)
   get_id_t get_id = nullptr;
   void *init_rank = nullptr;
   allgather_t allgather = nullptr;
@@ -798,6 +802,7 @@ extern "C++" Rccl &rccl() {
   r.allgather = (Rccl::allgather_t)dlsym(r.h, "ncclAllGather");
   r.destroy = (Rccl::destroy_t)dlsym(r.h, "ncclCommDestroy");
   r.errstr = (Rccl::errstr_t)dlsym(r.h, "ncclGetErrorString");
+  r.abort = (Rccl::destroy_t)dlsym(r.h, "ncclCommAbort");
   if (!r.get_id || !r.init_rank || !r.allgather || !r.destroy) r.err = "librccl.so lacks ncclGetUniqueId/CommInitRank/AllGather/CommDestroy";
   return r;
 }
@@ -845,7 +850,17 @@ int fpc_comm_init(fpc_engine *e, const void *id128, int rank, int world) {
   if (rc) { e->comm = nullptr; return comm_fail(e, "ncclCommInitRank", rc); }
   e->comm_rank = rank; e->comm_world = world;
   int rr;
-  if ((rr = dalloc(e, &e->d_gcounts, 2 * ((size_t)world + 1)))) return rr;
+  if (!e->d_gcounts || e->gcounts_world < world) {
+    if ((rr = dalloc(e, &e->d_gcounts, 3 * (size_t)world + 4))) return rr;     // zero-filled: epoch 0 is never a fresh record
+    e->gcounts_world = world;
+  }
+  // a new communicator starts at epoch 0 with every record cleared: a word left behind by an earlier communicator
+  // must never pass for a fresh one
+  e->comm_epoch = 0;
+  if (hipMemset(e->d_gcounts, 0, (3 * (size_t)e->gcounts_world + 4) * sizeof(long long)) != hipSuccess) {
+    (void)r.destroy(e->comm); e->comm = nullptr;      // local: nobody waits in a collective yet (tuples.init_comm MIN-reduces the verdicts)
+    return fail(e, FPC_ENODEVICE, "clearing the exchange records failed");
+  }
   e->gather_counts.assign(world, 0);
   return 0;
 #endif
@@ -863,6 +878,20 @@ int fpc_comm_destroy(fpc_engine *e) {
   return 0;
 }
 
+// The episode-end exchange.  What it guarantees: NO LOCAL FAILURE CAN STRAND A PEER.  Every rank that
+// enters goes through the same fixed sequence of collectives -- counts, status, payload -- and which of them run depends
+// only on values every rank has agreed on, never on a local success:
+//   1. counts round: (tuple count, buffer capacity, epoch) per rank.  A rank whose own HIP calls fail on the way in STILL
+//      enters the collective; its slot then carries the previous exchange's epoch, which the others recognise;
+//   2. status round, ALWAYS (one 8-byte all-gather per episode): 2 * epoch + 1 = "everything up to here worked on this
+//      rank" (counts read back, every peer's record fresh, send / receive buffers big enough).  Anything else -- 2 * epoch
+//      (failed) or a stale word (the status upload itself failed) -- makes EVERY rank leave before the payload
+//      collective, the failing one with its own error, the others with FPC_ECOMM naming the rank.  The protocol stays in
+//      lockstep, so the next exchange on the same communicator works (tests/test_comm_two_ranks_gpu.py);
+//   3. payload round.
+// Two windows cannot be closed by agreement: an error returned by an RCCL call itself, and a failure to read the status
+// words back (the rank cannot know whether the others go on).  There the rank aborts its communicator (ncclCommAbort, where
+// the library has it) so that peers blocked on it get an error instead of waiting, and returns; fpc_comm_init is needed again.
 int fpc_allgather_tuples(fpc_engine *e, int *counts_out, int *total_out) {
   if (!e || !counts_out || !total_out) return fail(e, FPC_EINVAL, "bad argument");
 #ifdef FPC_EMUL
@@ -872,31 +901,60 @@ int fpc_allgather_tuples(fpc_engine *e, int *counts_out, int *total_out) {
   USE_DEV(e);
   Rccl &r = rccl();
   const int W = e->comm_world;
-  // 1. counts: every rank contributes two int64: its tuple count, and the padded count its buffers already hold
-  //    (send side: tuple_cap; receive side: gather_cap / world) -- so every rank can tell whether ANY rank has to
-  //    grow a buffer for this exchange, i.e. whether the agreement round of step 1b is needed at all
-  long long mine[2] = {e->tuple_count, std::min<long long>(e->tuple_cap, (long long)(e->gather_cap / (size_t)W))};
-  HIPCHK(e, hipMemcpyAsync(e->d_gcounts + 2 * W, mine, sizeof(mine), hipMemcpyHostToDevice, e->stream));
-  int rc = r.allgather(e->d_gcounts + 2 * W, e->d_gcounts, 2, /*ncclInt64*/ 4, e->comm, e->stream);
-  if (rc) return comm_fail(e, "ncclAllGather(counts)", rc);
-  std::vector<long long> cnt2(2 * (size_t)W), cnt(W);
-  HIPCHK(e, hipMemcpyAsync(cnt2.data(), e->d_gcounts, cnt2.size() * sizeof(long long), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(e, hipStreamSynchronize(e->stream));
-  for (int i = 0; i < W; ++i) cnt[i] = cnt2[2 * (size_t)i];
-  long long mx = 1;
-  for (int i = 0; i < W; ++i) mx = std::max(mx, cnt[i]);
-  // 1b. room for the padded payload on both sides.  A rank that cannot make it must not simply return: the others
-  //     would block in the payload collective forever.  So nobody returns here; every rank reports a status word,
-  //     the words are all-gathered, and either all ranks go on or all of them leave with FPC_ECOMM / FPC_ENOMEM.
+  const long long epoch = ++e->comm_epoch;
   int local_rc = 0;
-  if (mx > e->tuple_cap) {     // the send buffer must hold the padded count: every rank knows mx, so each grows its own
+  std::string local_err;
+  auto note = [&](int rc) { if (rc && !local_rc) { local_rc = rc; local_err = e->err; } };
+  // a test can make one of this function's HIP calls fail (fpc_debug_comm_fault): the call is then NOT made
+  auto faulted = [&](int point) -> bool {
+    if (e->comm_fault != point) return false;
+    e->comm_fault = 0;
+    return true;
+  };
+  auto hip_ok = [&](hipError_t he, const char *what) -> bool {
+    if (he == hipSuccess) return true;
+    note(fail(e, FPC_ENODEVICE, "fpc_allgather_tuples: %s failed: %s", what, hipGetErrorString(he)));
+    return false;
+  };
+  auto abort_comm = [&](int rc) -> int {      // leave between collectives without agreement: peers must not wait for this rank
+    const std::string keep = e->err;
+    if (r.abort) (void)r.abort(e->comm); else (void)r.destroy(e->comm);
+    e->comm = nullptr;
+    e->err = keep + " (communicator aborted: fpc_comm_init is needed again)";
+    return rc;
+  };
+  long long *slot = e->d_gcounts + 3 * (size_t)W;       // this rank's counts record (3 words) ...
+  long long *stslot = slot + 3;                          // ... and its status word: a slot of its own, so that what a failed upload
+                                                         // leaves there is the PREVIOUS exchange's status word, never a fresh one
+  // 1. counts round
+  long long mine[3] = {e->tuple_count, std::min<long long>(e->tuple_cap, (long long)(e->gather_cap / (size_t)W)), epoch};
+  hip_ok(faulted(1) ? hipErrorUnknown : hipMemcpyAsync(slot, mine, sizeof(mine), hipMemcpyHostToDevice, e->stream), "counts upload");
+  int rc = r.allgather(slot, e->d_gcounts, 3, /*ncclInt64*/ 4, e->comm, e->stream);
+  if (rc) return abort_comm(comm_fail(e, "ncclAllGather(counts)", rc));
+  std::vector<long long> cnt3(3 * (size_t)W, 0), cnt(W, 0);
+  if (hip_ok(faulted(2) ? hipErrorUnknown : hipMemcpyAsync(cnt3.data(), e->d_gcounts, cnt3.size() * sizeof(long long), hipMemcpyDeviceToHost, e->stream), "counts read-back"))
+    hip_ok(hipStreamSynchronize(e->stream), "counts read-back");
+  long long mx = 1;
+  if (!local_rc) {
+    for (int i = 0; i < W; ++i) {
+      if (cnt3[3 * (size_t)i + 2] != epoch || cnt3[3 * (size_t)i] < 0) {
+        note(fail(e, FPC_ECOMM, "rank %d sent no fresh counts record for this exchange (its upload failed)", i));
+        break;
+      }
+      cnt[i] = cnt3[3 * (size_t)i];
+      mx = std::max(mx, cnt[i]);
+    }
+  }
+  // 1b. room for the padded payload on both sides (every rank knows mx, so each grows its own buffers)
+  if (!local_rc && mx > e->tuple_cap) {
     fpc_tuple *bigger = nullptr;
-    if ((local_rc = dalloc(e, &bigger, (size_t)mx)) == 0) {
+    if (faulted(3)) note(fail(e, FPC_ENOMEM, "fpc_allgather_tuples: growing the tuple send buffer failed (injected)"));
+    else note(dalloc(e, &bigger, (size_t)mx));
+    if (!local_rc) {
       hipError_t he = hipSuccess;
       if (e->tuple_count) he = hipMemcpyAsync(bigger, e->d_tuples, (size_t)e->tuple_count * sizeof(fpc_tuple), hipMemcpyDeviceToDevice, e->stream);
       if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
-      if (he != hipSuccess) {
-        local_rc = fail(e, FPC_ENODEVICE, "growing the tuple send buffer failed: %s", hipGetErrorString(he));
+      if (!hip_ok(he, "growing the tuple send buffer")) {
         (void)hipFree(bigger);
         e->allocs.erase(std::find(e->allocs.begin(), e->allocs.end(), (void *)bigger));
       } else {
@@ -907,37 +965,44 @@ int fpc_allgather_tuples(fpc_engine *e, int *counts_out, int *total_out) {
     }
   }
   const size_t want = (size_t)W * (size_t)mx;           // tuples in the receive buffer (size_t: world x capacity can pass 2^31)
-  if (local_rc == 0 && want > e->gather_cap) {
+  if (!local_rc && want > e->gather_cap) {
     if (e->d_gather) { (void)hipFree(e->d_gather); e->allocs.erase(std::find(e->allocs.begin(), e->allocs.end(), (void *)e->d_gather)); e->d_gather = nullptr; }
     e->gather_cap = 0;
-    if ((local_rc = dalloc(e, &e->d_gather, want)) == 0) e->gather_cap = want;
+    note(dalloc(e, &e->d_gather, want));
+    if (!local_rc) e->gather_cap = want;
   }
-  bool anyone_grows = false;
-  for (int i = 0; i < W; ++i) anyone_grows |= cnt2[2 * (size_t)i + 1] < mx;
-  if (anyone_grows) {
-    const std::string keep = e->err;                     // the local failure text, if any, survives the agreement round
-    long long st = local_rc == 0 ? 1 : 0;
-    std::vector<long long> sts(W, 0);
-    hipError_t he = hipMemcpyAsync(e->d_gcounts + 2 * W, &st, sizeof(st), hipMemcpyHostToDevice, e->stream);
-    if (he != hipSuccess) return fail(e, FPC_ENODEVICE, "status upload failed: %s", hipGetErrorString(he));
-    rc = r.allgather(e->d_gcounts + 2 * W, e->d_gcounts, 1, /*ncclInt64*/ 4, e->comm, e->stream);
-    if (rc) return comm_fail(e, "ncclAllGather(status)", rc);
-    HIPCHK(e, hipMemcpyAsync(sts.data(), e->d_gcounts, (size_t)W * sizeof(long long), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    if (local_rc) { e->err = keep; return local_rc; }
-    for (int i = 0; i < W; ++i)
-      if (!sts[i]) return fail(e, FPC_ECOMM, "rank %d could not make room for the padded tuple payload; no rank entered the payload collective", i);
-  }
-  // 2. payload, padded to the largest count: ONE collective per episode (latency-bound)
+  // 2. status round -- always
+  const long long good = 2 * epoch + 1;
+  long long st = local_rc == 0 ? good : 2 * epoch;
+  std::vector<long long> sts(W, 0);
+  hip_ok(faulted(4) ? hipErrorUnknown : hipMemcpyAsync(stslot, &st, sizeof(st), hipMemcpyHostToDevice, e->stream), "status upload");   // failed: the slot keeps a stale word
+  rc = r.allgather(stslot, e->d_gcounts, 1, /*ncclInt64*/ 4, e->comm, e->stream);
+  if (rc) return abort_comm(comm_fail(e, "ncclAllGather(status)", rc));
+  const int before = local_rc;
+  if (hip_ok(faulted(5) ? hipErrorUnknown : hipMemcpyAsync(sts.data(), e->d_gcounts, (size_t)W * sizeof(long long), hipMemcpyDeviceToHost, e->stream), "status read-back"))
+    hip_ok(hipStreamSynchronize(e->stream), "status read-back");
+  if (local_rc && !before) { e->err = local_err; return abort_comm(local_rc); }     // said "good", cannot see what the others said
+  if (local_rc) { e->err = local_err; return local_rc; }                              // the others saw this rank's word: nobody goes on
+  for (int i = 0; i < W; ++i)
+    if (sts[i] != good) return fail(e, FPC_ECOMM, "rank %d reported a failure before the payload collective; no rank entered it", i);
+  // 3. payload, padded to the largest count: ONE collective per episode (latency-bound)
   e->gather_stride = (int)mx;
   rc = r.allgather(e->d_tuples, e->d_gather, (size_t)mx * sizeof(fpc_tuple), /*ncclUint8*/ 1, e->comm, e->stream);
-  if (rc) return comm_fail(e, "ncclAllGather(tuples)", rc);
-  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (rc) return abort_comm(comm_fail(e, "ncclAllGather(tuples)", rc));
+  HIPCHK(e, hipStreamSynchronize(e->stream));            // behind the last collective: nobody waits for this rank any more
   int total = 0;
   for (int i = 0; i < W; ++i) { e->gather_counts[i] = (int)cnt[i]; counts_out[i] = (int)cnt[i]; total += (int)cnt[i]; }
   *total_out = total;
   return 0;
 #endif
+}
+
+// TEST HOOK: the next fpc_allgather_tuples on this engine treats one of its own HIP calls as failed --
+// 1 counts upload, 2 counts read-back, 3 send-buffer growth, 4 status upload, 5 status read-back (0 = none).
+int fpc_debug_comm_fault(fpc_engine *e, int point) {
+  if (!e || point < 0 || point > 5) return fail(e, FPC_EINVAL, "bad argument");
+  e->comm_fault = point;
+  return 0;
 }
 
 int fpc_gathered_read(fpc_engine *e, fpc_tuple *host_out, int first, int n) {

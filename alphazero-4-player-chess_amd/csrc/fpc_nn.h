@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(64) k_nchw_to_grid(const float *x, int n, int 
 struct BlobHeader {
   char magic[4];
   int32_t version, R, F, nblocks, dtype, A_ch, Np, Kp;
-  int32_t fc_layout;     // fragment order of the policy Linear's weights: 0 = 32x32x16 (k_fc), 1 = 16x16x32 (k_fc16)
+  int32_t fc_layout;     // fragment order of the policy Linear's weights: 0 = 32x32x16 (k_fc), 1 = 16x16x32 (k_fc16), 2 = 16x16x32 over Np = 384 * groups columns (k_fcw)
   int32_t pad[6];
 };
 static_assert(sizeof(BlobHeader) == 64, "header is 64 bytes");
@@ -433,9 +433,10 @@ struct NN {
   std::vector<ConvW> c1, c2;
   uint16_t *fcw = nullptr;
   float *fcb = nullptr, *vw = nullptr;
-  float *fc_part = nullptr;      // [slabs][Gpad][256] partial sums of k_fc (sized for 2*FC_SPLITK slabs per group)
-  int fc_G1 = 0, fc_s2 = FC_SPLITK;   // work decomposition chosen at load time (plan_fc)
-  int fc_layout = 0;                 // the loaded blob's weight fragment order: 0 -> k_fc, 1 -> k_fc16
+  float *fc_part = nullptr;      // [slabs][Gpad][256 | 384] partial sums of the policy Linear (sized for 2*FC_SPLITK slabs per column)
+  int fc_G1 = 0, fc_s1 = FC_SPLITK, fc_s2 = FC_SPLITK;   // work decomposition chosen at load time (plan_fc)
+  int fc_layout = 0;                 // the loaded blob's weight fragment order: 0 -> k_fc, 1 -> k_fc16, 2 -> k_fcw (256 x 384 block tiles)
+  int fc_gw = 256;                   // columns per column group (block tile width): 256, or FCW_COLS for layout 2
   unsigned char *towerW = nullptr;   // k_tower's weight stream: [(2*nblocks + 2) * 9 taps][32 KiB] in LDS-image order (F == 128)
   unsigned char *stemW = nullptr;    // [9 taps][8 KiB], same order
   float *towerB = nullptr;           // [2*nblocks + 2][256] (128 used)
@@ -492,7 +493,18 @@ struct NN {
   // Policy-Linear work decomposition (see k_fc): how many column groups get FC_SPLITK long blocks,
   // the rest getting twice as many half-length ones, so that the last round of blocks is full.
   // Blocks are dispatched in id order, one per CU: simulate that and keep the shortest makespan.
+  // Layout 2 (k_fcw): every column group of 384 gets the same number of K-splits, chosen so that all blocks run in ONE
+  // round (groups x splits <= CUs) with whole stages of 64 per block; plan_fcw() says whether such a split exists.
+  static int plan_fcw(int Np, int Kp, int cus) {
+    const int groups = Np / FCW_COLS, stages = Kp / 64;
+    int best = 0;
+    for (int sk = 1; sk <= 2 * FC_SPLITK && groups * sk <= cus; ++sk)
+      if (stages % sk == 0 && stages / sk >= 4) best = sk;
+    return best;
+  }
   void plan_fc() {
+    if (fc_layout == 2) { fc_G1 = Np / FCW_COLS; fc_s2 = fc_s1; return; }     // fc_s1 set by load()
+    fc_s1 = FC_SPLITK;
     const int groups = Np / 256, ks = Kp / 16, mt = (Gmax + 255) / 256;
     fc_s2 = (ks % (2 * FC_SPLITK * 8) == 0 && ks / (2 * FC_SPLITK) / 4 >= 4) ? 2 * FC_SPLITK : FC_SPLITK;
     fc_G1 = groups;
@@ -524,14 +536,25 @@ struct NN {
     if (h.version == 2 && h.fc_layout != 0) { *err = "weight blob version 2 carries a policy-Linear layout word (version 3 does)"; return FPC_EWEIGHTS; }
     if (h.R != dc.R || h.A_ch != dc.A_ch) { *err = "weight blob is for a different board size"; return FPC_EWEIGHTS; }
     if (h.dtype != dtype) { *err = "weight blob dtype differs from engine nn_dtype"; return FPC_EWEIGHTS; }
-    if (h.F % 64 || h.F < 64 || h.F > 512 || h.nblocks < 0 || h.Np % 256 || h.Kp % 512 || h.Kp < 1024 || h.Np < dc.A || h.Kp < dc.A) {
-      *err = "unsupported network shape in weight blob (hidden must be a multiple of 64, Np of 256, Kp of 512)";
+    if (h.fc_layout < 0 || h.fc_layout > 2) { *err = "unknown policy-Linear weight layout in weight blob"; return FPC_EWEIGHTS; }
+    if (h.F % 64 || h.F < 64 || h.F > 512 || h.nblocks < 0 || h.Np % (h.fc_layout == 2 ? FCW_COLS : 256) || h.Kp % 512 || h.Kp < 1024 || h.Np < dc.A || h.Kp < dc.A) {
+      *err = "unsupported network shape in weight blob (hidden must be a multiple of 64, Np of 256 -- 384 for fc_layout 2 --, Kp of 512)";
       return FPC_EWEIGHTS;
+    }
+    int fcw_split = 0;
+    if (h.fc_layout == 2) {
+      int cus = 256, dev = 0;
+      hipDeviceProp_t prop;
+      (void)hipGetDevice(&dev);
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+      fcw_split = plan_fcw(h.Np, h.Kp, cus);
+      if (!fcw_split) { *err = "weight blob fc_layout 2 (k_fcw): no one-round K-split for this shape on this device; export with fc_layout 1"; return FPC_EWEIGHTS; }
     }
     destroy();
     F = h.F; nblocks = h.nblocks; Np = h.Np; Kp = h.Kp;
-    if (h.fc_layout != 0 && h.fc_layout != 1) { *err = "unknown policy-Linear weight layout in weight blob"; return FPC_EWEIGHTS; }
     fc_layout = h.fc_layout;
+    fc_gw = fc_layout == 2 ? FCW_COLS : 256;
+    if (fc_layout == 2) fc_s1 = fcw_split;
     const unsigned char *base = (const unsigned char *)blob;
     uint64_t off = sizeof(BlobHeader);
     int rc = 0;
@@ -788,19 +811,21 @@ struct NN {
     if (logits_out) {            // null: legal-only policy head, the caller runs k_policy_gemv instead
       FcArgs f{};
       f.X = xfc; f.Wf = fcw; f.part = fc_part; f.Kp = Kp; f.Np = Np; f.ksteps = Kp / 16; f.Mtot = Gpad;
-      f.G1 = fc_G1; f.s1 = FC_SPLITK; f.s2 = fc_s2;
+      f.G1 = fc_G1; f.s1 = fc_s1; f.s2 = fc_s2;
       const int mtiles = (n + 255) / 256;
-      const int blocks = fc_G1 * FC_SPLITK + (Np / 256 - fc_G1) * fc_s2;
+      const int blocks = fc_G1 * fc_s1 + (Np / fc_gw - fc_G1) * fc_s2;
       bool &fattr = attr_fc[DT];
       if (!fattr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fc<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fc16<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fcw<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, FCW_LDS);
         fattr = true;
       }
-      if (fc_layout == 1) hipLaunchKernelGGL((k_fc16<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), FC_LDS, stream, f);
+      if (fc_layout == 2) hipLaunchKernelGGL((k_fcw<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), FCW_LDS, stream, f);
+      else if (fc_layout == 1) hipLaunchKernelGGL((k_fc16<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), FC_LDS, stream, f);
       else hipLaunchKernelGGL((k_fc<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), FC_LDS, stream, f);
       hipLaunchKernelGGL(k_fc_reduce, dim3((dc.A / 4 + 255) / 256, n), dim3(256), 0, stream, (const float *)fc_part, (const float *)fcb,
-                         fc_G1, FC_SPLITK, fc_s2, Gpad, dc.A, n, skip_dense ? (float *)nullptr : logits_out, d_stats);
+                         fc_G1, fc_s1, fc_s2, fc_gw, Gpad, dc.A, n, skip_dense ? (float *)nullptr : logits_out, d_stats);
       const hipError_t le = hipGetLastError();
       if (le != hipSuccess) { *err = std::string("k_fc launch failed: ") + hipGetErrorString(le); return FPC_ENODEVICE; }
     }
@@ -821,8 +846,8 @@ struct NN {
   }
   static_assert(2 * FC_SPLITK <= LOGIT_MAX_SLABS, "logit_at() requests at most LOGIT_MAX_SLABS slabs per column");
   LogitSrc logit_src(bool dense) const {
-    if (dense) return LogitSrc{d_logits, nullptr, nullptr, 0, 0, 0, 0};
-    return LogitSrc{nullptr, fc_part, fcb, fc_G1, FC_SPLITK, fc_s2, Gpad};
+    if (dense) return LogitSrc{d_logits, nullptr, nullptr, 0, 0, 0, 0, 256};
+    return LogitSrc{nullptr, fc_part, fcb, fc_G1, fc_s1, fc_s2, Gpad, fc_gw};
   }
   // ---- legal-only policy head --------------------------------------------------------------
   // one-time: row-major copy of the policy weights + the legal-logit buffer
@@ -832,8 +857,9 @@ struct NN {
     int rc;
     if ((rc = dmalloc(&fcw2, (size_t)Np * Kp, err)) || (rc = dmalloc(&d_ll, (size_t)Gmax * FPC_MAX_MOVES, err))) return rc;
     const long chunks = (long)Np * (Kp / 8);
-    if (dtype) hipLaunchKernelGGL((k_fc_unfrag<1>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)fcw, fcw2, Np, Kp, fc_layout);
-    else hipLaunchKernelGGL((k_fc_unfrag<0>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)fcw, fcw2, Np, Kp, fc_layout);
+    const int order = fc_layout == 0 ? 0 : 1;      // layout 2 is layout 1's fragment order over a wider Np
+    if (dtype) hipLaunchKernelGGL((k_fc_unfrag<1>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)fcw, fcw2, Np, Kp, order);
+    else hipLaunchKernelGGL((k_fc_unfrag<0>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)fcw, fcw2, Np, Kp, order);
     if (hipGetLastError() != hipSuccess) { *err = "k_fc_unfrag launch failed"; return FPC_ENODEVICE; }
     return 0;
   }

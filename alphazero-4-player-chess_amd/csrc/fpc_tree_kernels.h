@@ -1500,7 +1500,7 @@ __global__ void __launch_bounds__(SM_THREADS) k_softmax_partials(const float *lo
 // ================================================================================================
 constexpr int EXPAND_THREADS = 64;
 // Where a leaf's logits come from.  `dense` != null: a [G][A] f32 matrix (external evaluators; fpc_nn_forward).
-// Else: the policy Linear's split-K partial sums as k_fc16 left them -- `part` [slab][Mtot][256] f32 and the bias --
+// Else: the policy Linear's split-K partial sums as k_fc16 / k_fcw left them -- `part` [slab][Mtot][gw] f32 and the bias --
 // which the fused search never combines into a dense matrix: the softmax records come from k_fc_reduce, and the
 // expansion adds up the slabs of a column itself at the leaf's ~40 legal moves, in k_fc_reduce's order
 // (bias, then the group's slabs ascending: the same f32 additions, the same bits).
@@ -1509,16 +1509,17 @@ struct LogitSrc {
   const float *dense;
   const float *part, *bias;
   int G1, s1, s2, Mtot;      // column groups [0, G1) own s1 slabs each, the rest s2 (plan_fc)
+  int gw;                    // columns per group: 256 (k_fc / k_fc16) or 384 (k_fcw)
 };
 __device__ __forceinline__ float logit_at(const LogitSrc &L, int g, int A, int idx) {
   if (L.dense) return L.dense[(size_t)g * A + idx];
-  const int j = idx >> 8, col = idx & 255;                         // column group of 256 (fpc_fc.h)
+  const int j = L.gw == 256 ? idx >> 8 : idx / L.gw, col = idx - j * L.gw;   // column group (fpc_fc.h)
   const int base = j < L.G1 ? j * L.s1 : L.G1 * L.s1 + (j - L.G1) * L.s2, cnt = j < L.G1 ? L.s1 : L.s2;
   // all of a column's slabs are requested before the first is added (one round trip, not `cnt`): a group has at most
   // LOGIT_MAX_SLABS = 2 * FC_SPLITK of them (plan_fc)
   float p[LOGIT_MAX_SLABS];
 #pragma unroll
-  for (int k = 0; k < LOGIT_MAX_SLABS; ++k) p[k] = k < cnt ? L.part[((size_t)(base + k) * L.Mtot + g) * 256 + col] : 0.f;
+  for (int k = 0; k < LOGIT_MAX_SLABS; ++k) p[k] = k < cnt ? L.part[((size_t)(base + k) * L.Mtot + g) * L.gw + col] : 0.f;
   float v = L.bias[idx];
 #pragma unroll
   for (int k = 0; k < LOGIT_MAX_SLABS; ++k) v = k < cnt ? v + p[k] : v;

@@ -142,6 +142,7 @@ _SIGS = {
     "fpc_comm_available": (C.c_int, []),
     "fpc_nn_kernel": (C.c_char_p, [C.c_void_p]),
     "fpc_allgather_tuples": (C.c_int, [C.c_void_p, P(C.c_int), P(C.c_int)]),
+    "fpc_debug_comm_fault": (C.c_int, [C.c_void_p, C.c_int]),
     "fpc_gathered_read": (C.c_int, [C.c_void_p, P(Tuple), C.c_int, C.c_int]),
 }
 EXPORTS = sorted(_SIGS)
@@ -458,6 +459,10 @@ class Engine:
         buf = (C.c_char * 128).from_buffer_copy(bytes(id128))
         self._chk(self.L.fpc_comm_init(self.h, buf, rank, world))
         self.comm_world = world
+
+    def debug_comm_fault(self, point):
+        """TEST HOOK: the next allgather_tuples treats one of its own HIP calls as failed (include/fpc_engine.h)"""
+        self._chk(self.L.fpc_debug_comm_fault(self.h, point))
 
     def allgather_tuples_device(self):
         """episode end: RCCL all-gather of every rank's tuples, driven from the C++ host; the gathered

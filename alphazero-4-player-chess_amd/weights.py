@@ -41,12 +41,19 @@ def _conv_section(w, b, cin_pad, cout_pad, dtype):
     return [_to16(wt, dtype), bb.numpy().astype(np.float32).tobytes()]
 
 
-FC_LAYOUT = int(os.environ.get("FPC_FC_LAYOUT", "1"))      # 1: 16x16x32 fragment order (k_fc16, default); 0: 32x32x16 (k_fc)
+# Fragment order / block tile of the policy Linear: 2 = 16x16x32 fragments over 384-column groups (k_fcw: 256 x 384 block
+# tiles, one round of blocks; the default where its one-round K-split exists: the 14x14 board), 1 = the same fragment order
+# over 256-column groups (k_fc16, the default elsewhere), 0 = 32x32x16 (k_fc).  FPC_FC_LAYOUT forces one.
+FC_LAYOUT = int(os.environ["FPC_FC_LAYOUT"]) if "FPC_FC_LAYOUT" in os.environ else None
+
+
+def default_fc_layout(R):
+    return FC_LAYOUT if FC_LAYOUT is not None else (2 if R == 14 else 1)
+
 
 
 def export_weights(model, dtype=0, fc_layout=None):
     """model: ResNet in eval semantics.  dtype 0 = bf16, 1 = fp16.  Returns bytes."""
-    fc_layout = FC_LAYOUT if fc_layout is None else int(fc_layout)
     F = model.startBlock[0].weight.shape[0]
     nblocks = len(model.backBone)
     A_ch = model.policyHead[0].weight.shape[0]
@@ -55,7 +62,9 @@ def export_weights(model, dtype=0, fc_layout=None):
     RR = A // A_ch
     R = int(round(RR ** 0.5))
     assert R * R == RR and fc.weight.shape[1] == A
-    Np = (A + 255) // 256 * 256          # k_fc blocks own 256 columns
+    fc_layout = default_fc_layout(R) if fc_layout is None else int(fc_layout)
+    gw = 384 if fc_layout == 2 else 256
+    Np = (A + gw - 1) // gw * gw         # a block owns gw columns
     Kp = (A + 511) // 512 * 512      # k_fc: K/16 k-steps, split-K 4 (8 for the short blocks), 4 k-steps per stage, stages in pairs
     secs = []
     w, b = _fold(model.startBlock[0], model.startBlock[1])
@@ -81,7 +90,7 @@ def export_weights(model, dtype=0, fc_layout=None):
         # element (ks, nt, h, r, e) = W'[nt*32 + r][ks*16 + h*8 + e]
         wf = fwp.view(Np // 32, 32, Kp // 16, 2, 8).permute(2, 0, 3, 1, 4).contiguous()
     else:
-        # MFMA fragment order of k_fc16 (16x16x32): [kstep32][n_tile16][lane = 16*q + c][8],
+        # MFMA fragment order of k_fc16 / k_fcw (16x16x32): [kstep32][n_tile16][lane = 16*q + c][8],
         # element (ks, nt, q, c, e) = W'[nt*16 + c][ks*32 + q*8 + e]
         wf = fwp.view(Np // 16, 16, Kp // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
     del fwp

@@ -457,7 +457,8 @@ def main():
     peak = PEAK_TFLOPS[args.dtype]
     ach_tower = flops_tower / (tower_ms * 1e-3) / 1e12 if tower_ms > 0 else 0.0
     ach_fc = flops_fc / (fc_ms * 1e-3) / 1e12 if fc_ms > 0 else 0.0
-    Np, Kp = (A + 255) // 256 * 256, (A + 511) // 512 * 512
+    fc_gw = 384 if weights.default_fc_layout(R) == 2 else 256
+    Np, Kp = (A + fc_gw - 1) // fc_gw * fc_gw, (A + 511) // 512 * 512
     # algorithmic bytes of the policy Linear inside the fused search: the 16-bit weight matrix read once + X read once.
     # (The dense f32 logits matrix -- 4 G A bytes -- is no longer written there: k_fc_reduce leaves the softmax records,
     # the expansion reads the split-K slabs at the legal moves.  FPC_DENSE_LOGITS=1 brings the write back.)
@@ -480,7 +481,7 @@ def main():
                   "k_tower256": "k_tower256 (residual tower megakernel, hidden 256, one wave per SIMD, 2-slab LDS weight ring; developer knob)",
                   "k_towerw": "k_towerw (residual tower megakernel, hidden %d, two waves per SIMD, weights L2 -> registers, LDS-resident activations)" % F,
                   "k_conv3x3": "k_conv3x3 x %d launches (per-layer implicit GEMM, activations through L2) + k_value_tail" % (2 * Nb + 3)}.get(nn_kernel, nn_kernel)
-    fc_kernels = ["k_fc16" if weights.FC_LAYOUT == 1 else "k_fc", "k_fc_reduce"]   # the Linear (by the weight layout exported) and its split-K reduce
+    fc_kernels = [{0: "k_fc", 1: "k_fc16", 2: "k_fcw"}[weights.default_fc_layout(R)], "k_fc_reduce"]   # the Linear (by the weight layout exported) and its split-K reduce
     tree_ms = sel_ms + exp_ms
     label = workload_label(G, sims, Nb, F, R)
     out = {

@@ -227,6 +227,14 @@ int fpc_comm_destroy(fpc_engine *e);
  * arrays over xGMI.  counts_out: host [world].  The gathered tuples stay on the device, rank-major
  * (rank r's tuples first .. counts_out[r] of them), and are read with fpc_gathered_read. */
 int fpc_allgather_tuples(fpc_engine *e, int *counts_out, int *total_out);
+/* Between the two sits an 8-byte status all-gather that ALWAYS runs: a rank on which anything local failed (an upload, a
+ * read-back, growing a buffer) still goes through the counts and the status collective, every rank then leaves before
+ * the payload collective -- the failing one with its own error, the others with FPC_ECOMM naming it -- and the
+ * communicator stays usable.  Only an error of an RCCL call itself, or a failed read-back of the status words, ends
+ * with the communicator aborted (ncclCommAbort) and fpc_comm_init needed again.
+ * TEST HOOK: the next fpc_allgather_tuples treats one of its own HIP calls as failed -- 1 counts upload, 2 counts
+ * read-back, 3 send-buffer growth, 4 status upload, 5 status read-back; 0 clears it. */
+int fpc_debug_comm_fault(fpc_engine *e, int point);
 int fpc_gathered_read(fpc_engine *e, fpc_tuple *host_out, int first, int n);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------- */

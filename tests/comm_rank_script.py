@@ -44,9 +44,26 @@ else:
         time.sleep(0.01)
     uid = open(idfile, "rb").read()
 eng.comm_init(uid, rank, world)
-for rep in range(2):          # second exchange: every buffer is big enough now, the status round must not be needed
-    counts, garr, total = eng.allgather_tuples()
+# FPC_TEST_COMM_FAULT = "<rank>:<point>": that rank makes one of the HIP calls of its FIRST exchange fail
+# (fpc_debug_comm_fault).  Points 1-4 are routed through the status round: BOTH ranks must come back with an error from
+# exchange 0 -- nobody waits in the payload collective -- and the communicator must still work for exchanges 1 and 2.
+# Point 5 (the status words cannot be read back) ends with the communicator aborted on that rank and an error on the other.
+fault = os.environ.get("FPC_TEST_COMM_FAULT", "")
+frank, fpoint = (int(x) for x in fault.split(":")) if fault else (-1, 0)
+if frank == rank:
+    eng.debug_comm_fault(fpoint)
+reps = 3 if fault else 2
+for rep in range(reps):       # without a fault -- second exchange: every buffer is big enough now
+    try:
+        counts, garr, total = eng.allgather_tuples()
+    except RuntimeError as ex:
+        if not fault:
+            raise
+        open(os.path.join(d, "error_%d_%d.txt" % (rank, rep)), "w").write(str(ex))
+        if fpoint == 5:
+            break             # communicator gone on the faulting rank; the peer was told (ncclCommAbort)
+        continue
     open(os.path.join(d, "gathered_%d_%d.bin" % (rank, rep)), "wb").write(bytes(memoryview(garr).cast("B")[:total * 1280]))
     open(os.path.join(d, "counts_%d_%d.txt" % (rank, rep)), "w").write(" ".join(str(int(c)) for c in counts))
 eng.close()
-print("rank %d ok: %d local tuples, %d gathered" % (rank, n, total))
+print("rank %d ok: %d local tuples" % (rank, n))

@@ -4,7 +4,7 @@
 // RCCL refuses two ranks on one GPU ("duplicate GPU"), and this pool hands out one-GPU boxes, so the engine's own
 // episode-end exchange (fpc_comm_init / fpc_allgather_tuples: counts + capacities -> buffer growth -> status round ->
 // max-padded payload, csrc/fpc_engine.cpp) has only ever run with a one-rank communicator.  This stand-in exports the
-// five librccl entry points the engine binds with dlsym and implements ncclAllGather for N PROCESSES ON ONE BOX by way
+// librccl entry points the engine binds with dlsym (the five it needs + ncclCommAbort) and implements ncclAllGather for N PROCESSES ON ONE BOX by way
 // of files in a directory both ranks know (FILE_COLLECTIVE_DIR): every rank copies its send buffer device -> host,
 // publishes it as <dir>/<seq>_<rank>.bin (write + rename), waits for every rank's file of that sequence number, and
 // copies them host -> device into the receive buffer in rank order.  Blocking, like the real collective from the
@@ -59,7 +59,17 @@ int ncclCommInitRank(void **comm, int world, Id128 id, int rank) {
 }
 
 int ncclCommDestroy(void *comm) { delete (Comm *)comm; return 0; }
-const char *ncclGetErrorString(int rc) { return rc == 0 ? "ok" : rc == 5 ? "invalid usage" : rc == 1 ? "unhandled hip error" : "file collective: timeout or i/o error"; }
+// ncclCommAbort: the rank leaves; a marker file makes every peer's current or next wait return ncclRemoteError (6)
+// instead of running into its deadline -- the one property of the real call the engine relies on
+int ncclCommAbort(void *comm) {
+  Comm *c = (Comm *)comm;
+  if (c) {
+    if (FILE *f = fopen((c->dir + "/aborted").c_str(), "wb")) fclose(f);
+    delete c;
+  }
+  return 0;
+}
+const char *ncclGetErrorString(int rc) { return rc == 0 ? "ok" : rc == 5 ? "invalid usage" : rc == 1 ? "unhandled hip error" : rc == 6 ? "remote error: a peer aborted its communicator" : "file collective: timeout or i/o error"; }
 
 int ncclAllGather(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t stream) {
   Comm *c = (Comm *)comm;
@@ -85,6 +95,7 @@ int ncclAllGather(const void *send, void *recv, size_t count, int dtype, void *c
     const char *src = mine.data();
     if (r != c->rank) {
       while (!read_file(p, other, bytes)) {
+        if (FILE *a = fopen((c->dir + "/aborted").c_str(), "rb")) { fclose(a); return 6; }
         if (std::chrono::steady_clock::now() > deadline) return 3;
         std::this_thread::sleep_for(std::chrono::milliseconds(2));
       }

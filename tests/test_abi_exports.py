@@ -22,7 +22,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(fpc_ffi.EXPORTS)
-    assert lib.fpc_abi_version() == 6
+    assert lib.fpc_abi_version() == 7
 
 
 def test_pod_layouts():

@@ -250,14 +250,15 @@ def test_tower256_forms_agree(dtype, monkeypatch):
 
 @pytest.mark.parametrize("R,dtype", [(14, 1), (8, 0)])
 def test_both_policy_linear_kernels_meet_the_fp32_network(R, dtype):
-    """k_fc16 (16x16x32, [k32][tile16] weight order: the default) and k_fc (32x32x16, fc_layout = 0 in the blob):
+    """k_fcw (256 x 384 block tiles, fc_layout = 2: the default at 14x14; at 8x8 its 12 column groups x 8 K-splits), k_fc16
+    (16x16x32, [k32][tile16] weight order, 256-column groups: the default elsewhere) and k_fc (32x32x16, fc_layout = 0):
     each within the operand type's bound of the fp32 torch network, and within rounding of each other."""
     import torch
     import weights
     m = _model(R, 2, 128, seed=9)
     boards = _positions(R, 24)
     outs = []
-    for layout in (1, 0):
+    for layout in (2, 1, 0):
         eng = make_engine("gpu", R, INV_OF[R], max_games=len(boards), max_sims=4, nn_dtype=dtype)
         eng.load_weights(weights.export_weights(m, dtype, fc_layout=layout))
         enc = np.concatenate([eng.encode([b]) for b in boards])
@@ -274,13 +275,14 @@ def test_both_policy_linear_kernels_meet_the_fp32_network(R, dtype):
     for o in outs:
         assert np.abs(o - ref_l.numpy()).max() < tol
     assert np.abs(outs[0] - outs[1]).max() < 2e-5      # same operands, f32 accumulation in another order
+    assert np.abs(outs[0] - outs[2]).max() < 2e-5
 
 
 def test_headline_shape_256_rows_every_row_vs_fp32_network():
     """the headline shape -- 14x14, hidden 128, M = 256 rows -- held against the fp32 torch network
     ROW BY ROW.  256 positions from the reference's recorded playouts fill every row tile of the policy Linear
-    (k_fc16's tiles 0..15 / k_fc's 0..7), plan_fc's long and short blocks at Mtot = 256 (126 MB of split-K slabs) and
-    k_fc_reduce's chunk records at that size; both weight fragment orders; logits AND values at north_star's 1e-3 for
+    (k_fcw's / k_fc16's tiles 0..15, k_fc's 0..7), k_fcw's 248 one-round blocks and plan_fc's long and short blocks at Mtot = 256 and
+    k_fc_reduce's chunk records at that size; all three policy-Linear kernels; logits AND values at north_star's 1e-3 for
     every single row (the searches at this size only check properties that hold for wrong logits too)."""
     import torch
     import weights
@@ -290,7 +292,7 @@ def test_headline_shape_256_rows_every_row_vs_fp32_network():
     assert len(boards) == n
     ref_l = ref_v = enc = None
     outs = []
-    for layout in (1, 0):
+    for layout in (2, 1, 0):
         eng = make_engine("gpu", R, INV_OF[R], max_games=n, max_sims=4, nn_dtype=dtype)
         eng.load_weights(weights.export_weights(m, dtype, fc_layout=layout))
         if enc is None:
@@ -315,6 +317,7 @@ def test_headline_shape_256_rows_every_row_vs_fp32_network():
         outs.append(lg)
         eng.close()
     assert np.abs(outs[0] - outs[1]).max() < 2e-5                # same operands, f32 accumulation in another order
+    assert np.abs(outs[0] - outs[2]).max() < 2e-5
 
 
 @pytest.mark.parametrize("blocks,hidden,sims", [(10, 128, 400), (20, 256, 800)], ids=["configs1", "configs3"])

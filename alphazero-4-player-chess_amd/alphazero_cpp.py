@@ -350,6 +350,14 @@ class Move:                             # move.h:23-49, move.cpp:23-104, wrapper
         return "Move: %s -> %s" % (self._from, self._to)
 
 
+class SimpleBoardState:                 # engine/board.h:491-497, wrapper.cpp:68-73 (read-write attributes)
+    def __init__(self):
+        self.turn = None
+        self.pieces = []
+        self.castlingRights = []
+        self.attackedSquares = {}
+
+
 class MemoryEntry:                      # board.h:133-140: Board held BY VALUE + the pi tensor
     def __init__(self, state, action):
         self.state = state._copy()
@@ -731,10 +739,41 @@ class Board:                            # board.h:18-131, wrapper.cpp:165-226
         pod = engine().take_action([self._b], [flat])[0]
         return Board._wrap(pod, like=self)
 
-    def GetSimpleState(self):
-        raise RuntimeError("GetSimpleState feeds the pygame reviewer only and is outside the engine's scope")
+    # ---- the attacked-square queries (wrapper.cpp:201-206; board.cpp:50-57, :120-232): one device launch per call
+    def _attack_maps(self):
+        return engine().attack_maps([self._b])[0]          # [6][R*R] 0/1: colours 0..3, teams 0..1
 
-    GetAttackedSquaresPlayers = GetAttackedSquaresTeams = IsAttackedByPlayer = GetSimpleState
+    def GetAttackedSquaresPlayers(self):                    # board.cpp:120-140: {colour: [location, ...]} row-major;
+        m = self._attack_maps()                             # a colour that attacks nothing has no entry
+        out = {}
+        for c in range(4):
+            sq = [int(x) for x in m[c].nonzero()[0]]
+            if sq:
+                out[PlayerColor(c)] = [BoardLocation._from_sq(q) for q in sq]
+        return out
+
+    def GetAttackedSquaresTeams(self):                      # board.cpp:212-232, the engine's IsAttackedByTeam per square
+        m = self._attack_maps()
+        out = {}
+        for t in range(2):
+            sq = [int(x) for x in m[4 + t].nonzero()[0]]
+            if sq:
+                out[Team(t)] = [BoardLocation._from_sq(q) for q in sq]
+        return out
+
+    def IsAttackedByPlayer(self, location, color):          # board.cpp:142-210
+        if not location.Present():
+            return False                                    # every probe around a missing location is missing too
+        return bool(self._attack_maps()[int(color)][location._sq()])
+
+    def GetSimpleState(self):                               # board.cpp:50-57
+        st = SimpleBoardState()
+        st.turn = self.GetTurn()
+        st.pieces = self.GetPieces()
+        # castling_rights_ is CastlingRights(false, false) unless the constructor was handed rights (engine/board.cpp:1178-1191)
+        st.castlingRights = [CastlingRights(bool(self._b.castle[c] & 1), bool(self._b.castle[c] & 2)) for c in range(4)]
+        st.attackedSquares = self.GetAttackedSquaresPlayers()
+        return st
 
     @staticmethod
     def ParseActionspace(actionspaces_1d, turn):      # board.cpp:257-263

@@ -416,6 +416,22 @@ int fpc_boards_take_action(fpc_engine *e, const fpc_board *boards, const int *fl
   return fetch_errs(e, n, "board");
 }
 
+int fpc_boards_attack_maps(fpc_engine *e, const fpc_board *boards, int n, uint8_t *out_host) {
+  if (!e || !boards || !out_host || n < 0) return fail(e, FPC_EINVAL, "bad argument");
+  USE_DEV(e);
+  if (n == 0) return 0;
+  int r;
+  if ((r = check_boards(e, boards, n))) return r;
+  if ((r = ensure_board_scratch(e, n))) return r;
+  HIPCHK(e, hipMemcpyAsync(e->d_boards, boards, (size_t)n * sizeof(fpc_board), hipMemcpyHostToDevice, e->stream));
+  uint8_t *d_maps = reinterpret_cast<uint8_t *>(e->d_dense);       // [n][24][RR] f32 of scratch: room for [n][6][RR] bytes
+  FPC_LAUNCH(k_attack_maps, n, 64, e->stream, e->dc, (const fpc_board *)e->d_boards, n, d_maps);
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipMemcpyAsync(out_host, d_maps, (size_t)n * 6 * e->dc.RR, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return 0;
+}
+
 int fpc_boards_encode(fpc_engine *e, const fpc_board *boards, int n, float *out_host) {
   if (!e || !boards || !out_host || n < 0) return fail(e, FPC_EINVAL, "bad argument");
   USE_DEV(e);

@@ -2,6 +2,7 @@
 // concurrent game (block = 1 wave, grid = games), board state staged in LDS.
 //
 //   k_board_ops      batched Board::GetLegalMoves / GetGameResult / TakeAction / encode / mask
+//   k_attack_maps    GetAttackedSquaresPlayers / GetAttackedSquaresTeams / IsAttackedByPlayer (wrapper.cpp:201-206)
 //   k_select         Node::ChooseLeaf: PUCT descent (wave argmax), lazy leaf-board materialisation,
 //                    GetGameResult + GetLegalMoves on the leaf, terminal backup        (node.cpp:19-78)
 //   k_encode         Board::GetEncodedStates incl. the batch-wide rot90                 (board.cpp:305-356)
@@ -1000,6 +1001,73 @@ __global__ void __launch_bounds__(64) k_board_ops(DevCfg c, fpc_board *boards, i
   }
   lds_store_board(&s, &boards[g]);
   if (lane == 0) err[g] = e;
+}
+
+// ================================================================================================
+// k_attack_maps: the attacked-square queries of the binding surface (wrapper.cpp:201-206), one wave per position:
+//   maps 0..3  fpchess::Board::IsAttackedByPlayer(location, colour) (src/cpp/board.cpp:142-210) -- its OWN probe set, not
+//              the engine's: pawns / knights / kings on the array (BoardLocation::Present(), engine/board.h:194-201), and
+//              eight rays that end at the ARRAY edge, i.e. run through the cut corners; the first piece on a ray attacks
+//              if it is a bishop (diagonals), rook (lines) or queen -- of whichever colour it is, which is the colour's bit;
+//   maps 4..5  chess::Board::IsAttackedByTeam(team, location) (engine/board.cpp:606-787) = attacked_virtual on the position.
+// Every row x column of the array is a location, cut corners included (the double loops of board.cpp:120-140, :212-232).
+// out: [n][6][RR] bytes, 1 = attacked.
+// ================================================================================================
+__device__ inline uint32_t attacked_by_players(const fpc_board *b, const DevCfg &c, int sq) {
+  const int R = c.R, lr = row_of(c, sq), lc = sq - lr * R;
+  uint32_t m = 0;
+  for (int k = 0; k < 8; ++k) {                       // the eight neighbours: pawns (:152-161) and kings (:200-207)
+    const int kk = k < 4 ? k : k + 1;
+    const int dr = kk / 3 - 1, dc = kk % 3 - 1;
+    const int r = lr + dr, cc = lc + dc;
+    if (!in_array(c, r, cc)) continue;
+    const uint8_t p = b->sq[r * R + cc];
+    if (!present(p)) continue;
+    const int col = colour_of(p), t = type_of(p);
+    if (t == KING) m |= 1u << col;
+    // PawnAttacks(pawn, colour, location), engine/board.cpp:583-604: (row_diff, col_diff) = location - pawn = (-dr, -dc)
+    const bool patt = (col == 0 && dr == 1 && dc != 0) || (col == 1 && dc == -1 && dr != 0) || (col == 2 && dr == -1 && dc != 0) ||
+                      (col == 3 && dc == 1 && dr != 0);
+    if (t == PAWN && patt) m |= 1u << col;
+  }
+  for (int k = 0; k < 8; ++k) {                       // knights (:164-171)
+    const int dr = (k & 4) ? ((k & 2) ? 1 : -1) : ((k & 2) ? 2 : -2);
+    const int dc = (k & 4) ? ((k & 1) ? 2 : -2) : ((k & 1) ? 1 : -1);
+    const int r = lr + dr, cc = lc + dc;
+    if (!in_array(c, r, cc)) continue;
+    const uint8_t p = b->sq[r * R + cc];
+    if (present(p) && type_of(p) == KNIGHT) m |= 1u << colour_of(p);
+  }
+  for (int k = 0; k < 8; ++k) {                       // sliders (:174-197): the first piece on each ray
+    const int kk = k < 4 ? k : k + 1;
+    const int dr = kk / 3 - 1, dc = kk % 3 - 1;
+    const bool diag = dr != 0 && dc != 0;
+    int r = lr + dr, cc = lc + dc;
+    while (in_array(c, r, cc)) {
+      const uint8_t p = b->sq[r * R + cc];
+      if (present(p)) {
+        const int t = type_of(p);
+        if (t == QUEEN || (t == BISHOP && diag) || (t == ROOK && !diag)) m |= 1u << colour_of(p);
+        break;
+      }
+      r += dr; cc += dc;
+    }
+  }
+  return m;
+}
+
+__global__ void __launch_bounds__(64) k_attack_maps(DevCfg c, const fpc_board *boards, int n, uint8_t *out) {
+  __shared__ WaveLds s;
+  const int g = blockIdx.x;
+  if (g >= n) return;
+  lds_load_board(&s, &boards[g]);
+  uint8_t *o = out + (size_t)g * 6 * c.RR;
+  for (int sq = lane_id(); sq < c.RR; sq += 64) {
+    const uint32_t pm = attacked_by_players(&s.b, c, sq);
+    for (int col = 0; col < 4; ++col) o[col * c.RR + sq] = (uint8_t)((pm >> col) & 1u);
+    for (int team = 0; team < 2; ++team)
+      o[(4 + team) * c.RR + sq] = attacked_virtual(&s.b, c, FPC_NO_SQ, FPC_NO_SQ, 0, FPC_NO_SQ, FPC_NO_SQ, 0, sq, team) ? 1 : 0;
+  }
 }
 
 // ================================================================================================

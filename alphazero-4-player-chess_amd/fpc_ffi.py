@@ -143,6 +143,7 @@ _SIGS = {
     "fpc_nn_kernel": (C.c_char_p, [C.c_void_p]),
     "fpc_allgather_tuples": (C.c_int, [C.c_void_p, P(C.c_int), P(C.c_int)]),
     "fpc_debug_comm_fault": (C.c_int, [C.c_void_p, C.c_int]),
+    "fpc_boards_attack_maps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "fpc_gathered_read": (C.c_int, [C.c_void_p, P(Tuple), C.c_int, C.c_int]),
 }
 EXPORTS = sorted(_SIGS)
@@ -297,6 +298,13 @@ class Engine:
         n = len(boards)
         out = np.zeros((n, 24, self.R, self.R), dtype=np.float32)
         self._chk(self.L.fpc_boards_encode(self.h, self._arr(boards), n, out.ctypes.data))
+        return out
+
+    def attack_maps(self, boards):
+        """[n][6][R*R] uint8: attacked-square maps by colour (0..3, Board::IsAttackedByPlayer) and by team (4..5)"""
+        n = len(boards)
+        out = np.zeros((n, 6, self.R * self.R), dtype=np.uint8)
+        self._chk(self.L.fpc_boards_attack_maps(self.h, self._arr(boards), n, out.ctypes.data))
         return out
 
     def legal_mask(self, boards):

@@ -119,6 +119,10 @@ int fpc_boards_take_action(fpc_engine *e, const fpc_board *boards, const int *fl
 int fpc_boards_encode(fpc_engine *e, const fpc_board *boards, int n, float *out_host);
 /* FourPlayerChess.get_legal_moves_mask (four_player_chess_board.py:36-56): out_host [n,A_ch,R,R] f32 */
 int fpc_boards_legal_mask(fpc_engine *e, fpc_board *boards, int n, float *out_host);
+/* Board::GetAttackedSquaresPlayers / GetAttackedSquaresTeams / IsAttackedByPlayer (wrapper.cpp:204-206; board.cpp:120-232):
+ * out_host [n][6][R*R] bytes, 1 = attacked -- maps 0..3 by colour (fpchess IsAttackedByPlayer: its own probe set, rays
+ * through the cut corners), maps 4..5 by team (the engine's IsAttackedByTeam); every row x column of the array */
+int fpc_boards_attack_maps(fpc_engine *e, const fpc_board *boards, int n, uint8_t *out_host);
 /* Board::CalculateHeuristic (engine/board.cpp:1263-1292), pure host arithmetic on the POD */
 int fpc_board_heuristic(const fpc_board *b, int team);
 

@@ -570,7 +570,74 @@ int orc_legal_moves(orc_board *b, int R, int INV, orc_move *out, int cap) { retu
 int orc_game_result(orc_board *b, int R, int INV, int player) { return game_result(b, R, INV, player); }
 int orc_is_king_in_check(const orc_board *b, int R, int INV, int colour) { return king_in_check(b, R, INV, colour); }
 int orc_is_attacked_by_team(const orc_board *b, int R, int INV, int team, int sq) { return attacked_by_team(b, R, INV, team, sq); }
+// fpchess::Board::IsAttackedByPlayer (src/cpp/board.cpp:142-210) -- NOT the engine's IsAttackedByTeam: its own probe
+// set, bounded by BoardLocation::Present() only (engine/board.h:194-201: inside the ARRAY), so its rays run THROUGH the
+// cut corners, and the queried location may itself lie in one (GetAttackedSquaresPlayers sweeps every row x column).
+bool attacked_by_player(const orc_board *b, int R, int sq, int colour) {
+  const int lr = sq / R, lc = sq % R;
+  static const int eight[8][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}, {1, 1}, {1, -1}, {-1, 1}, {-1, -1}};   // board.cpp:152-153 (= :176, :201)
+  // pawns (:152-161): a pawn of that colour on one of the eight neighbours that PawnAttacks the location
+  // (engine/board.cpp:583-604: row_diff / col_diff = location - pawn)
+  for (const auto &d : eight) {
+    const int r = lr + d[0], c = lc + d[1];
+    if (!in_array(R, r, c)) continue;
+    const uint8_t p = b->sq[r * R + c];
+    if (!present(p) || colour_of(p) != colour || type_of(p) != PAWN) continue;
+    const int row_diff = lr - r, col_diff = lc - c;
+    bool att = false;
+    switch (colour) {
+      case 0: att = row_diff == -1 && (col_diff == 1 || col_diff == -1); break;
+      case 1: att = col_diff == 1 && (row_diff == 1 || row_diff == -1); break;
+      case 2: att = row_diff == 1 && (col_diff == 1 || col_diff == -1); break;
+      default: att = col_diff == -1 && (row_diff == 1 || row_diff == -1); break;
+    }
+    if (att) return true;
+  }
+  // knights (:164-171)
+  static const int knight[8][2] = {{1, 2}, {2, 1}, {-1, -2}, {-2, -1}, {1, -2}, {2, -1}, {-1, 2}, {-2, 1}};
+  for (const auto &d : knight) {
+    const int r = lr + d[0], c = lc + d[1];
+    if (!in_array(R, r, c)) continue;
+    const uint8_t p = b->sq[r * R + c];
+    if (present(p) && colour_of(p) == colour && type_of(p) == KNIGHT) return true;
+  }
+  // bishops, rooks, queens (:174-197): the first piece on each of the eight rays
+  for (const auto &d : eight) {
+    int r = lr + d[0], c = lc + d[1];
+    while (in_array(R, r, c)) {
+      const uint8_t p = b->sq[r * R + c];
+      if (present(p)) {
+        if (colour_of(p) != colour) break;
+        const int t = type_of(p);
+        if (t != BISHOP && t != ROOK && t != QUEEN) break;
+        if (t == BISHOP && (d[0] == 0 || d[1] == 0)) break;
+        if (t == ROOK && (d[0] != 0 && d[1] != 0)) break;
+        return true;
+      }
+      r += d[0]; c += d[1];
+    }
+  }
+  // kings (:200-207)
+  for (const auto &d : eight) {
+    const int r = lr + d[0], c = lc + d[1];
+    if (!in_array(R, r, c)) continue;
+    const uint8_t p = b->sq[r * R + c];
+    if (present(p) && colour_of(p) == colour && type_of(p) == KING) return true;
+  }
+  return false;
+}
+
 int orc_make_move(orc_board *b, int R, const orc_move *m) { (void)R; return make_move(b, m); }
+int orc_is_attacked_by_player(const orc_board *b, int R, int sq, int colour) { return attacked_by_player(b, R, sq, colour); }
+// GetAttackedSquaresPlayers (board.cpp:120-140) and GetAttackedSquaresTeams (:212-232) as byte maps over EVERY row x
+// column of the array (cut corners included, as the reference's double loop): out[k][sq] = 1 if attacked, k = colour
+// 0..3 (IsAttackedByPlayer), then 4 + team (the engine's IsAttackedByTeam)
+void orc_attack_maps(const orc_board *b, int R, int INV, uint8_t *out /* [6][R*R] */) {
+  for (int sq = 0; sq < R * R; ++sq) {
+    for (int colour = 0; colour < 4; ++colour) out[colour * R * R + sq] = attacked_by_player(b, R, sq, colour) ? 1 : 0;
+    for (int team = 0; team < 2; ++team) out[(4 + team) * R * R + sq] = attacked_by_team(b, R, INV, team, sq) ? 1 : 0;
+  }
+}
 int orc_take_action_flat(orc_board *b, int R, int flat) {   // board.cpp:234-239 + move.cpp:39-61
   int from, to;
   orc_flat_to_move(R, flat, &from, &to);

@@ -81,6 +81,10 @@ int  orc_legal_moves(orc_board *b, int R, int INV, orc_move *out, int cap);    /
 int  orc_game_result(orc_board *b, int R, int INV, int player /* -1 = turn */);/* board.cpp:891 */
 int  orc_is_king_in_check(const orc_board *b, int R, int INV, int colour);     /* board.cpp:941 */
 int  orc_is_attacked_by_team(const orc_board *b, int R, int INV, int team, int sq);
+int  orc_is_attacked_by_player(const orc_board *b, int R, int sq, int colour);  /* fpchess board.cpp:142-210 */
+/* GetAttackedSquaresPlayers / GetAttackedSquaresTeams (board.cpp:120-140, :212-232): out[6][R*R] byte maps over every
+ * row x column of the array, maps 0..3 by colour (IsAttackedByPlayer), 4..5 by team (engine IsAttackedByTeam) */
+void orc_attack_maps(const orc_board *b, int R, int INV, uint8_t *out);
 int  orc_make_move(orc_board *b, int R, const orc_move *m);  /* 0 ok, -1 "piece missing" throw */
 int  orc_take_action_flat(orc_board *b, int R, int flat);    /* Move(flat)+MakeMove on b itself */
 int  orc_heuristic(const orc_board *b, int team);            /* engine/board.cpp:1263-1292 */

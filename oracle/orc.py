@@ -132,6 +132,18 @@ def take_action(b, R, flat):
     return nb, rc
 
 
+def attack_maps(b, R, INV):
+    """[6][R*R] 0/1 maps: colours 0..3 (IsAttackedByPlayer), teams 0..1 (IsAttackedByTeam); every square of the array"""
+    import numpy as np
+    out = np.zeros((6, R * R), dtype=np.uint8)
+    lib().orc_attack_maps(C.byref(b), R, INV, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def is_attacked_by_player(b, R, sq, colour):
+    return bool(lib().orc_is_attacked_by_player(C.byref(b), R, sq, colour))
+
+
 def encode(boards, R):
     import numpy as np
     n = len(boards)

@@ -276,3 +276,38 @@ def case_play_loop_prefetch(backend, R, games=6, plies=4, sims=24):
         other = moved.TakeAction(lm[0])
         assert other._gr_cache is None
     return checked
+
+
+def case_attacked_square_methods(backend, R, max_cases=24):
+    """Board.GetAttackedSquaresPlayers / GetAttackedSquaresTeams / IsAttackedByPlayer / GetSimpleState through the
+    drop-in surface (wrapper.cpp:201-206), the way the reference's reviewer calls them, against the golden dump of the
+    real reference (tests/golden/ref_attack_r*.json.gz): dict keys, locations and their order."""
+    from engine_cases import load_attack_golden
+    az = setup(backend, R)
+    from four_player_chess_board import FourPlayerChess
+    g = load_attack_golden(R)
+    done = 0
+    for c in [c for c in g["cases"] if "by_player" in c][:max_cases]:
+        l2p = {}
+        for colour, col in enumerate(c["pl"]):
+            for sq, typ in col:
+                l2p[az.BoardLocation(sq // R, sq % R)] = az.Piece(az.PlayerColor(colour), az.PieceType(typ))
+        b = FourPlayerChess(az.Player(az.PlayerColor(c["turn"])), l2p)
+        sqs = lambda locs: [int(l.GetRow()) * R + int(l.GetCol()) for l in locs]
+        players = b.GetAttackedSquaresPlayers()
+        assert {str(int(k)): sqs(v) for k, v in players.items()} == c["players"]
+        assert all(isinstance(k, az.PlayerColor) for k in players)
+        teams = b.GetAttackedSquaresTeams()
+        assert {str(int(k)): sqs(v) for k, v in teams.items()} == c["teams"]
+        for colour in range(4):
+            for sq in range(0, R * R, 7):
+                assert b.IsAttackedByPlayer(az.BoardLocation(sq // R, sq % R), az.PlayerColor(colour)) == bool(c["by_player"][colour][sq])
+        assert b.IsAttackedByPlayer(az.BoardLocation(), az.PlayerColor.RED) is False
+        st = b.GetSimpleState()
+        assert int(st.turn.GetColor()) == c["simple"]["turn"]
+        assert {str(int(k)): sqs(v) for k, v in st.attackedSquares.items()} == c["simple"]["attacked"]
+        got = [[[int(pp.GetLocation().GetRow()) * R + int(pp.GetLocation().GetCol()), int(pp.GetPiece().GetPieceType())] for pp in col] for col in st.pieces]
+        assert got == c["simple"]["pieces"]                 # through the constructor: the reference's own list order
+        assert len(st.castlingRights) == 4 and not any(cr.Kingside() or cr.Queenside() for cr in st.castlingRights)
+        done += 1
+    return done

@@ -488,3 +488,37 @@ def case_fixed_rules_vs_oracle(backend, R, n_games=6, plies=60, sims=40, seed=31
         orc.set_root_noise(None)
         eng.close()
     return n_promo, n_castle
+
+
+def load_attack_golden(R):
+    import gzip
+    import json
+    import os
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_attack_r%d.json.gz" % R), "rt") as f:
+        return json.load(f)
+
+
+def case_attack_maps(backend, R, stride=1):
+    """fpc_boards_attack_maps (k_attack_maps) against the golden dump of the reference's GetAttackedSquaresPlayers /
+    GetAttackedSquaresTeams / IsAttackedByPlayer (oracle/gen_attack_golden.py) AND against the oracle's maps, bit for bit;
+    the boards come back untouched (the queries are const in the reference)."""
+    from oracle import orc
+    g = load_attack_golden(R)
+    cases = g["cases"][::stride]
+    INV = {8: 2, 14: 3}[R]
+    eng = make_engine(backend, R, INV, max_games=8, max_sims=4)
+    boards = [fpc_ffi.board_from_lists(R, c["turn"], c["pl"]) for c in cases]
+    before = [bytes(b) for b in boards]
+    maps = eng.attack_maps(boards)
+    assert [bytes(b) for b in boards] == before
+    for c, m in zip(cases, maps):
+        for colour in range(4):
+            assert [int(x) for x in np.nonzero(m[colour])[0]] == c["players"].get(str(colour), []), (c["pos"], colour)
+        for team in range(2):
+            assert [int(x) for x in np.nonzero(m[4 + team])[0]] == c["teams"].get(str(team), []), (c["pos"], team)
+        if "by_player" in c:
+            assert m[:4].tolist() == c["by_player"], c["pos"]
+        ob = orc.board_from_lists(R, c["turn"], c["pl"])
+        assert np.array_equal(m, orc.attack_maps(ob, R, INV)), c["pos"]
+    eng.close()
+    return len(cases)

@@ -50,3 +50,8 @@ def test_the_reference_mcts_py_itself_runs_on_the_shim():
 @pytest.mark.parametrize("R", [8, 14])
 def test_play_loop_takes_successors_from_one_batched_prefetch(R):
     assert dc.case_play_loop_prefetch("emul", R) >= 6
+
+
+@pytest.mark.parametrize("R", [8, 14])
+def test_attacked_square_methods_of_the_binding_surface(R):
+    assert dc.case_attacked_square_methods("emul", R, max_cases=10) >= 10

@@ -113,3 +113,8 @@ def test_host_node_forms_reproduce_reference_searches(R):
     """Node.ChooseLeaf / SelectChild / Backpropagate(Nodes) / ExpandNodes as host methods (wrapper.cpp:233-253);
     board operations on the GPU through the C-ABI; golden visit counts of the real reference."""
     assert dc.case_host_tree("gpu", R, max_cases=3, max_sims=100) >= 1
+
+
+@pytest.mark.parametrize("R", [8, 14])
+def test_attacked_square_methods_of_the_binding_surface(R):
+    assert dc.case_attacked_square_methods("gpu", R, max_cases=24) >= 24

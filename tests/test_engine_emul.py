@@ -97,3 +97,8 @@ def test_step_entry_points_refuse_bad_calls():
         assert list(res["sims_done"]) == [3, 3] and list(res["root_n"]) == [4, 4]
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("R", [8, 14])
+def test_attack_maps_vs_reference_and_oracle(R):
+    assert ec.case_attack_maps("emul", R, stride=4) >= 80

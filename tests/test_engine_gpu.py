@@ -67,3 +67,10 @@ def test_fixed_rules_and_root_noise_vs_oracle(R, rules):
     n_promo, n_castle = ec.case_fixed_rules_vs_oracle("gpu", R, n_games=12, plies=90 if R == 8 else 40, sims=60, rules=rules)
     if rules & 8:
         assert (n_promo > 0) if R == 8 else (n_castle > 0)
+
+
+@pytest.mark.parametrize("R", [8, 14])
+def test_attack_maps_vs_reference_and_oracle(R):
+    """wrapper.cpp:201-206 on the device (k_attack_maps): every golden position of ref_attack_r*.json.gz, maps by colour
+    and by team against the real reference's dump and against the oracle, bit for bit"""
+    assert ec.case_attack_maps("gpu", R) >= 300

@@ -180,3 +180,38 @@ def test_expf_accuracy():
     rel = np.abs(got.astype(np.float64) - ref) / ref
     assert rel.max() < 2.5e-7          # <= ~2 ulp
     assert L.orc_expf(0.0) == 1.0 and L.orc_expf(float("-inf")) == 0.0 and L.orc_expf(-90.0) == 0.0
+
+
+@pytest.mark.parametrize("R", [8, 14])
+def test_attacked_square_queries_vs_reference(R):
+    """wrapper.cpp:201-206 (GetAttackedSquaresPlayers / GetAttackedSquaresTeams / IsAttackedByPlayer / GetSimpleState):
+    the oracle's restatement against tests/golden/ref_attack_r{R}.json.gz, dumped from the real reference build
+    (oracle/gen_attack_golden.py) -- per colour / team the reported squares IN THE REFERENCE'S ORDER (row-major; a
+    colour or team without an attacked square has no entry), and the single-square query for every (square, colour)."""
+    import gzip
+    import json
+    import os
+    import numpy as np
+    INV = {8: 2, 14: 3}[R]
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_attack_r%d.json.gz" % R), "rt") as f:
+        g = json.load(f)
+    assert g["R"] == R and len(g["cases"]) >= 300
+    n_single = 0
+    for case in g["cases"]:
+        b = orc.board_from_lists(R, case["turn"], case["pl"])
+        maps = orc.attack_maps(b, R, INV)
+        for colour in range(4):
+            want = case["players"].get(str(colour), [])
+            assert [int(x) for x in np.nonzero(maps[colour])[0]] == want, (case["pos"], colour)
+        for team in range(2):
+            want = case["teams"].get(str(team), [])
+            assert [int(x) for x in np.nonzero(maps[4 + team])[0]] == want, (case["pos"], team)
+        if "by_player" in case:
+            n_single += 1
+            for colour in range(4):
+                got = [1 if orc.is_attacked_by_player(b, R, sq, colour) else 0 for sq in range(R * R)]
+                assert got == case["by_player"][colour], (case["pos"], colour)
+            assert case["simple"]["turn"] == case["turn"] and case["simple"]["attacked"] == case["players"]
+            # (the generator rebuilt the position through the reference's constructor, which orders the piece lists its own way)
+            assert [sorted(col) for col in case["simple"]["pieces"]] == [sorted(col) for col in case["pl"]]
+    assert n_single >= 30

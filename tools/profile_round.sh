@@ -13,6 +13,8 @@ stats() {   # stats <name> <bench flags...>
   rm -rf gpurun_out/prof_$name
   timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$name -- python3 bench.py "$@" > gpurun_out/$TAG/${name}_bench.json 2> gpurun_out/$TAG/${name}_bench.err
   cp gpurun_out/prof_$name/*/*kernel_stats.csv gpurun_out/$TAG/${name}_kernel_stats.csv 2>/dev/null || echo "no stats for $name"
+  # the line was produced under the profiler: its roofline fractions from the kernel trace of this very run
+  python3 tools/trace_roofline.py gpurun_out/$TAG/${name}_bench.json gpurun_out/$TAG/${name}_kernel_stats.csv
   echo "== $name"; head -8 gpurun_out/$TAG/${name}_kernel_stats.csv | cut -d, -f1-5; cut -c1-300 gpurun_out/$TAG/${name}_bench.json
 }
 if [[ $PART == *A* ]]; then

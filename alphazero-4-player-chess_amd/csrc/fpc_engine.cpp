@@ -580,7 +580,7 @@ int fpc_search_run(fpc_engine *e, int sims) {
     mark(e, 1);
     e->nn.mark_fn = [](void *ctx, int tag) { mark((fpc_engine *)ctx, tag); };
     e->nn.mark_ctx = e;
-    const bool dense = getenv("FPC_DENSE_LOGITS") != nullptr;    // developer knob (A/B): the dense [G][A] logits matrix is written as well
+    const bool dense = getenv("FPC_DEV_KNOBS") && atoi(getenv("FPC_DEV_KNOBS")) != 0 && getenv("FPC_DENSE_LOGITS") != nullptr;    // developer knob (A/B, with FPC_DEV_KNOBS=1): the dense [G][A] logits matrix is written as well
     int r = e->policy_mode == FPC_POLICY_LEGAL ? e->nn.forward_legal(e->G, e->t, &e->err) : e->nn.forward(e->G, dense, &e->err);
     e->nn.mark_fn = nullptr;
     if (r) return r;
@@ -1095,7 +1095,7 @@ const char *fpc_nn_kernel(fpc_engine *e) {
   return "";
 #else
   if (!e || !e->nn.loaded) return "";
-  return e->nn.use_towerw ? "k_towerw" : e->nn.use_tower ? "k_tower" : e->nn.tower256_v1 ? "k_tower256" : "k_conv3x3";
+  return e->nn.use_towerw ? "k_towerw" : e->nn.use_tower ? "k_tower" : "k_conv3x3";
 #endif
 }
 void *fpc_stream(fpc_engine *e) { return e ? (void *)e->stream : nullptr; }

@@ -1,32 +1,27 @@
-// fpc_fc.h -- k_fc / k_fc16: the policy Linear (net.py:25: A -> A, 553 M weights at 14x14 = 1.1 GB in 16 bit)
-// as a weight-streaming GEMM for M = 256 rows: every weight byte is used once per forward, so the
-// kernel is bound by the HBM stream (1.11 GB per launch; 283 GFLOP ride on it).
-//
-//   * W is stored by the exporter in MFMA FRAGMENT ORDER  [kstep16][n_tile32][lane 64][8 elems]
-//     (k-step major: all waves advance through K together, so what the chip reads at any moment is a
-//     few contiguous regions spread over every HBM channel): one v_mfma_f32_32x32x16 B-operand of a
-//     wave is one contiguous, perfectly coalesced 1-KiB read that goes straight from HBM into VGPRs --
-//     the weights never touch LDS and are never shared between waves.
-//   * A block is 4 waves, one per SIMD, each with the whole register file: a wave owns 64 output columns
-//     for all 256 rows = 8 x 2 accumulator tiles of 32x32 (256 AGPRs).  Every activation fragment read
-//     from LDS feeds two MFMAs (0.5 KiB of LDS per MFMA; the 8-wave / 32-column version of round 1 paid
-//     1 KiB and stalled on the LDS queue), and the fragment reads run a whole k-step (16 MFMAs, 512
-//     cycles) ahead of their use.
+// fpc_fc.h -- the policy Linear (net.py:25: A -> A, 553 M weights at 14x14 = 1.1 GB in 16 bit) as a weight-streaming
+// GEMM for M = 256 rows: every weight byte is used once per forward, so the kernels are bound by the HBM stream
+// (1.11 GB per launch; 283 GFLOP ride on it) and by whatever else travels the same L1 / L2 / LDS-DMA path.
+//   k_fcw   (round 5; blob fc_layout 2; the default at 14x14): 256 x 384 block tiles, one round of blocks -- see below.
+//   k_fc16  (round 3; fc_layout 1; the other board sizes): 256 x 256 block tiles, long and short blocks in two rounds.
+//   (k_fc, rounds 1-4: the same on v_mfma_f32_32x32x16 with its own fragment order -- retired in round 5; what it
+//   established is kept in the notes below.)
+// Common to both:
+//   * W is stored by the exporter in MFMA FRAGMENT ORDER  [k-step of 32][column tile of 16][lane = 16 q + c][8]
+//     (element (k32, nt, q, c, e) = W'[16 nt + c][32 k32 + 8 q + e]; k-step major: all waves advance through K together,
+//     so what the chip reads at any moment is a few contiguous regions spread over every HBM channel): one A operand of a
+//     wave is one contiguous, perfectly coalesced 1-KiB piece.
+//   * A block is 4 waves, one per SIMD, each with the whole register file; a wave owns 64 (k_fc16) or 96 (k_fcw) output
+//     columns for all 256 rows, issued as W x X^T: a lane owns ONE activation row and four consecutive output columns
+//     per accumulator, so a partial tile leaves as one 16-byte store per lane.
 //   * The weight pieces carry the non-temporal hint: 1.1 GB read once per launch would otherwise push the
-//     activations, the tower's weights and the tree out of L2 / MALL (same-box A/B: +2.6 % on the whole step,
-//     8 us of it in this kernel, 5 in k_tower, 2 in the tree kernels).
+//     activations, the tower's weights and the tree out of L2 / MALL (same-box A/B: +2.6 % on the whole step).
 //   * Both operands arrive by LDS-DMA (global_load_lds_dwordx4, no VGPR hop): the activations X[256][K]
-//     (12 MB, L2 resident, re-read by every column group) in full 128-byte lines into three 32 KiB stage
-//     buffers shared by the block (XOR-swizzled through the source address), the weights into a private
-//     16 KiB ring per wave from which each lane reads back exactly the 16 bytes it stored.  Both streams
-//     run two stages ahead (64 KiB of weights in flight per CU).
-//   * Work decomposition: column group j (256 columns) x K-split i.  Groups [0, G1) are cut into s1
-//     K-splits, the remaining groups into s2 = 2*s1 half-length ones, G1 chosen by the host so that
-//     the short blocks fill the tail of the last round (368 equal blocks on 256 CUs would idle 28 %).
-//     Block ids put the K-split in the low bits, so one XCD (id mod 8) only ever walks one K window
-//     of X and keeps it in its own L2.
-//   * Every block writes its f32 partial slab [Mtot][256]; k_fc_reduce adds a group's slabs and the
-//     bias in a fixed order (deterministic, no atomics).
+//     (12 MB, L2 resident, re-read by every column group) in full 128-byte lines into 32 KiB stage buffers shared by
+//     the block (XOR-swizzled through the source address), the weights into a private ring per wave from which each
+//     lane reads back exactly the 16 bytes it stored.
+//   * Work = column group x K-split; block ids put the K-split in the low bits, so one XCD (id mod 8) only ever walks
+//     one K window of X and keeps it in its own L2.  Every block writes its f32 partial slab [Mtot][group width];
+//     k_fc_reduce adds a group's slabs and the bias in a fixed order (deterministic, no atomics).
 //   * The first MFMA on every accumulator takes C = 0 as an inline constant.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -74,164 +69,16 @@ __device__ __forceinline__ void fc_dma_nt(const void *gsrc_uniform, uint32_t lan
                : "=&s"(keep) : "v"(lane_off), "s"(gsrc_uniform), "s"(lds_addr_uniform) : "memory");
 }
 
-template <int DT>
-__global__ void __launch_bounds__(FC_THREADS, 1) k_fc(FcArgs g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [3 X buffers][4 per-wave weight rings]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // block id -> (column group, K-split, slab)
-  const int nbig = g.G1 * g.s1;
-  const int id = blockIdx.x;
-  const bool big = id < nbig;
-  const int idr = big ? id : id - nbig;
-  const int sk = big ? g.s1 : g.s2;
-  const int group = big ? idr / sk : g.G1 + idr / sk;
-  const int split = idr % sk;
-  const int ntile = group * 8 + wave * 2;         // this wave's two 32-column tiles: ntile, ntile + 1
-  const int KS = g.ksteps / sk;                   // k-steps (of 16) handled by this block; multiple of 8
-  const int ks0 = split * KS;
-  const int S = KS / 4;                           // stages of BK = 64 (even, >= 4)
-  const long mrow0 = (long)blockIdx.y * 256;
-  // weight stream of this wave: fragment (k-step k, tile ntile + n) = 1 KiB at wbase + (k * Np/32 + n) KiB
-  const unsigned char *wbase = reinterpret_cast<const unsigned char *>(g.Wf) + ((long)ks0 * (g.Np / 32) + ntile) * 1024;
-  const long wkstep = (long)(g.Np / 32) * 1024;
-  const uint32_t wlane = (uint32_t)lane * 16u;
-  // activation staging: this wave brings rows [64 wave, 64 wave + 64) of every stage: 8 pieces of 8 rows x
-  // 128 B (full lines).  The LDS image is XOR-swizzled (lds_off<64>); a DMA piece lands lane-linear, so
-  // the swizzle goes on the SOURCE: LDS slot (row, c) must receive logical chunk c ^ ((row >> 1) & 7).
-  const unsigned char *xbase = reinterpret_cast<const unsigned char *>(g.X) + ((mrow0 + wave * 64) * g.Kp + (long)ks0 * 16) * 2;
-  const long xpiece = 8L * g.Kp * 2;              // bytes between consecutive pieces (8 rows)
-  uint32_t xlane[2];                              // per-lane source offset for even / odd pieces
-#pragma unroll
-  for (int par = 0; par < 2; ++par) {
-    const int j = (lane & 7) ^ ((par * 4 + (lane >> 4)) & 7);
-    xlane[par] = (uint32_t)((lane >> 3) * g.Kp * 2 + j * 16);
-  }
-  const uint32_t lds_x = 0, lds_w = (uint32_t)(3 * FC_XBUF + wave * FC_WRING);
-  const unsigned char *wr = smem + 3 * FC_XBUF + wave * FC_WRING + lane * 16;   // this lane's 16 B of a ring fragment
-
-  f32x16_t acc[8][2];
-  u32x4_t xf[2][8], wf[2][2];   // activation / weight fragments of the current and the next k-step
-  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-  const std::integral_constant<int, 0> c0{};
-  const std::integral_constant<int, 1> c1{};
-  const std::integral_constant<int, 2> c2{};
-  const std::integral_constant<int, 3> c3{};
-
-  // DMA issue.  Stage indices past the end are clamped: the stream then re-reads the last stage into
-  // slots nobody reads any more, which keeps the issue pattern -- and with it every vmcnt count below --
-  // the same from the first to the last stage.
-  auto issue_x = [&](int s, int p) {              // piece p (8 rows) of activation stage s
-    const int sc = s < S ? s : S - 1;
-    fc_dma(xbase + (long)p * xpiece + (long)sc * 128, xlane[p & 1],
-           (uint32_t)__builtin_amdgcn_readfirstlane(lds_x + (s % 3) * FC_XBUF + (wave * 64 + p * 8) * 128));
-  };
-  auto issue_w = [&](int s, int ks) {             // both column tiles of k-step ks of stage s
-    const int sc = s < S ? s : S - 1;
-    const unsigned char *src = wbase + (long)(4 * sc + ks) * wkstep;
-    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(lds_w + ((s & 1) * 8 + ks * 2) * 1024);
-    fc_dma2_nt(src, wlane, dst);
-  };
-  auto xfrag = [&](int b, int t, const unsigned char *ab, int ks) {
-    xf[b][t] = *reinterpret_cast<const u32x4_t *>(ab + lds_off<64>(t * 32 + (lane & 31), ks * 2 + (lane >> 5)));
-  };
-  auto wfrag = [&](int b, int s, int ks) {
-    wf[b][0] = *reinterpret_cast<const u32x4_t *>(wr + ((s & 1) * 8 + ks * 2) * 1024);
-    wf[b][1] = *reinterpret_cast<const u32x4_t *>(wr + ((s & 1) * 8 + ks * 2 + 1) * 1024);
-  };
-
-  // One k-step of stage s: 16 MFMAs on xf / wf [KSI & 1] in 8 groups of 2 (one row tile x two column
-  // tiles) with the fragment reads of the NEXT k-step spread between the groups (order pinned), then
-  // this k-step's share of the stream two stages ahead:
-  //   k-steps 0, 1: four activation pieces of stage s + 2 each (buffer (s + 2) % 3, free since the barrier
-  //                 of stage s - 1); every k-step: the two weight fragments (s + 2, KSI) into the ring slots
-  //                 that (s, KSI) just vacated.
-  // Both streams run the SAME two stages ahead on purpose: vmcnt retires in issue order, so waiting for a
-  // young activation piece would otherwise force every older, deeper weight fragment to have landed and
-  // cut the weight prefetch to a fraction of its ring (that is what held round 1's kernel at 4 TB/s).
-  // Issue pattern per stage: 6, 6, 2, 2 pieces.  Counted waits (pieces issued after the one needed):
-  //   before reading the weights of (s, KSI + 1), issued at (s - 2, KSI + 1): 20 / 24 / 28 for KSI = 0 / 1 / 2;
-  //   k-step 3: the activations of stage s + 1 (last piece issued at (s - 1, 1)) and the weights of (s + 1, 0):
-  //   20, then THE stage barrier -- every wave's pieces of stage s + 1 have landed and every wave has its
-  //   last fragments of stage s in registers.
-  auto kstep = [&](auto ks_c, auto z_c, int s) {
-    constexpr int KSI = decltype(ks_c)::value;
-    constexpr bool Z = decltype(z_c)::value != 0;
-    constexpr int CUR = KSI & 1, NXT = CUR ^ 1;
-    if (KSI == 0) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    if (KSI == 1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    if (KSI == 2) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
-    if (KSI == 3) { asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); __syncthreads(); }
-    const unsigned char *ab = smem + ((KSI == 3 ? s + 1 : s) % 3) * FC_XBUF;
-    constexpr int KSN = KSI == 3 ? 0 : KSI + 1;
-    __builtin_amdgcn_sched_barrier(0);
-    wfrag(NXT, KSI == 3 ? s + 1 : s, KSN);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      acc[t][0] = E16<DT>::mfma(xf[CUR][t], wf[CUR][0], Z ? zero16 : acc[t][0]);
-      acc[t][1] = E16<DT>::mfma(xf[CUR][t], wf[CUR][1], Z ? zero16 : acc[t][1]);
-      __builtin_amdgcn_sched_barrier(0);
-      xfrag(NXT, t, ab, KSN);
-      if (KSI < 2 && (t & 1)) issue_x(s + 2, KSI * 4 + (t >> 1));
-      if (t == 7) issue_w(s + 2, KSI);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  // prologue: stages 0 and 1 of both streams, then the fragments of (0, 0)
-#pragma unroll
-  for (int p = 0; p < 8; ++p) issue_x(0, p);
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) issue_w(0, ks);
-#pragma unroll
-  for (int p = 0; p < 8; ++p) issue_x(1, p);
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) issue_w(1, ks);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-#pragma unroll
-  for (int t = 0; t < 8; ++t) xfrag(0, t, smem, 0);
-  wfrag(0, 0, 0);
-
-  kstep(c0, c1, 0);                               // (0, 0): C = 0
-  kstep(c1, c0, 0);
-  kstep(c2, c0, 0);
-  kstep(c3, c0, 0);
-#pragma unroll 1
-  for (int s = 1; s < S; ++s) {
-    kstep(c0, c0, s);
-    kstep(c1, c0, s);
-    kstep(c2, c0, s);
-    kstep(c3, c0, s);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail pieces: nothing may still target LDS at exit
-
-  const int slab = big ? id : nbig + idr;
-  float *out = g.part + ((long)slab * g.Mtot + mrow0) * 256;
-#pragma unroll
-  for (int t = 0; t < 8; ++t)
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const int col = wave * 64 + n * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        out[(long)m * 256 + col] = acc[t][n][r];
-      }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------
-// k_fc16: the same Linear on v_mfma_f32_16x16x32 (the shape the chip holds the higher clock on under load,
-// MI355X_MICROARCH.md "DVFS give-back" item 7; k_tower uses it for the same reason).  Same decomposition, same
-// LDS map, same two DMA streams two stages ahead, same bytes of LDS read per FLOP (20 fragment reads per 1 024
-// matrix-pipe cycles).  What differs:
-//   * the product is issued as W x X^T: a lane owns ONE activation row and four consecutive output columns per
-//     accumulator, so a partial tile goes out as one 16-byte store per lane (64 stores per wave instead of 256);
-//   * the weight fragment order is [k-step of 32][column tile of 16][lane = 16 q + c][8]:
-//     element (k32, nt, q, c, e) = W'[16 nt + c][32 k32 + 8 q + e]  (weights.py writes it; blob header fc_layout = 1);
+// k_fc16: the Linear on v_mfma_f32_16x16x32 (the shape the chip holds the higher clock on under load,
+// MI355X_MICROARCH.md "DVFS give-back" item 7; k_tower uses it for the same reason) with 256 x 256 block tiles:
+//   * a wave owns 64 columns x 256 rows = 16 x 4 accumulator tiles (256 AGPRs); every activation fragment read from LDS
+//     feeds four MFMAs, and the fragment reads run a whole k-step ahead of their use (two sets of 16);
+//   * three 32 KiB activation stages + a 16 KiB weight ring per wave (2 stages x 2 k-steps x 4 tiles); BOTH streams run
+//     the same two stages ahead: vmcnt retires in issue order, so waiting for a young activation piece would otherwise
+//     force every older, deeper weight fragment to have landed and cut the weight prefetch to a fraction of its ring;
+//   * column groups [0, G1) are cut into s1 K-splits, the remaining groups into s2 = 2 * s1 half-length ones, G1
+//     chosen by the host so that the short blocks fill the tail of the last round (plan_fc);
 //   * a k-step is 32 deep: 64 MFMAs on 16 activation fragments x 4 weight fragments; 8 DMA pieces per k-step in the
 //     fixed order  X, W, W, X, X, W, W, X  (the weight pieces in pairs behind one M0 write).  Counted waits:
 //     first k-step of a stage: the weights of its second k-step were issued three k-steps ago; behind their last

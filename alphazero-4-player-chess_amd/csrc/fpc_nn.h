@@ -25,7 +25,6 @@
 
 #include "fpc_tree_kernels.h"
 #include "fpc_tower.h"
-#include "fpc_tower256.h"
 #include "fpc_towerw.h"
 
 namespace fpc {
@@ -264,16 +263,13 @@ namespace fpc {
 // shares (a game with 90 legal moves does not hold one CU three times longer than one with 30).
 // ================================================================================================
 template <int DT>
-__global__ void __launch_bounds__(256) k_fc_unfrag(const uint16_t *Wf, uint16_t *W2, int Np, int Kp, int layout) {
-  // one thread per 16-byte chunk of the row-major matrix: (n, k8) <- fragment order [ks][nt][lane][8]
-  // (layout 0: k-steps of 16, tiles of 32 columns, lane = 32 h + r; layout 1: k-steps of 32, tiles of 16, lane = 16 q + c)
+__global__ void __launch_bounds__(256) k_fc_unfrag(const uint16_t *Wf, uint16_t *W2, int Np, int Kp) {
+  // one thread per 16-byte chunk of the row-major matrix: (n, k8) <- fragment order [k-step of 32][tile of 16 columns][lane = 16 q + c][8]
   const long c = (long)blockIdx.x * 256 + threadIdx.x;
   const long chunks = (long)Np * (Kp / 8);
   if (c >= chunks) return;
   const int n = (int)(c / (Kp / 8)), k8 = (int)(c % (Kp / 8));
-  const int ks = k8 >> 1, h = k8 & 1, nt = n >> 5, n32 = n & 31;
-  const long src = layout == 0 ? (((long)ks * (Np / 32) + nt) * 64 + (h * 32 + n32)) * 8
-                               : (((long)(k8 >> 2) * (Np / 16) + (n >> 4)) * 64 + ((k8 & 3) * 16 + (n & 15))) * 8;
+  const long src = (((long)(k8 >> 2) * (Np / 16) + (n >> 4)) * 64 + ((k8 & 3) * 16 + (n & 15))) * 8;
   *reinterpret_cast<u32x4_t *>(W2 + (long)n * Kp + (long)k8 * 8) = *reinterpret_cast<const u32x4_t *>(Wf + src);
 }
 
@@ -393,19 +389,19 @@ __global__ void __launch_bounds__(64) k_nchw_to_grid(const float *x, int n, int 
 
 // ------------------------------------------------------------------------------------------------
 // weight blob (written by alphazero-4-player-chess_amd/weights.py):
-//   header  : char magic[4]="FPCW"; int32 version (2: fc_layout 0 only; 3: fc_layout valid), R, F, nblocks, dtype, A_ch, Np, Kp, fc_layout; pad to 64 B
+//   header  : char magic[4]="FPCW"; int32 version (3; version 2 = the retired 32x32x16 fragment order of rounds 1-4: refused), R, F, nblocks, dtype, A_ch, Np, Kp, fc_layout; pad to 64 B
 //   sections, each 64-B aligned, in this order:
 //     stem   w16[9][Fp][32]     b f32[Fp]          (Fp = F rounded up to 128)
 //     block i: c1 w16[9][Fp][F] b f32[Fp] ; c2 w16[9][Fp][F] b f32[Fp]
 //     policy conv w16[9][128][F] b f32[128]
 //     value  conv w16[9][128][F] b f32[128]  (both heads: Cout zero-padded to the 128-wide tile)
-//     policy fc   w16 in MFMA fragment order [Kp/16][Np/32][64 lanes][8] (lane = 32*(k/8%2) + n%32)   b f32[Np]
+//     policy fc   w16 in MFMA fragment order [Kp/32][Np/16][64 lanes][8] (lane = 16*(k/8%4) + n%16; Np = 256 * groups for fc_layout 1, 384 * groups for 2)   b f32[Np]
 //     value  fc   w f32[R*R][32] b f32[1]
 // ------------------------------------------------------------------------------------------------
 struct BlobHeader {
   char magic[4];
   int32_t version, R, F, nblocks, dtype, A_ch, Np, Kp;
-  int32_t fc_layout;     // fragment order of the policy Linear's weights: 0 = 32x32x16 (k_fc), 1 = 16x16x32 (k_fc16), 2 = 16x16x32 over Np = 384 * groups columns (k_fcw)
+  int32_t fc_layout;     // policy Linear: 1 = 16x16x32 fragments over 256-column groups (k_fc16), 2 = over 384-column groups (k_fcw); 0 (32x32x16, k_fc) retired in round 5
   int32_t pad[6];
 };
 static_assert(sizeof(BlobHeader) == 64, "header is 64 bytes");
@@ -435,22 +431,21 @@ struct NN {
   float *fcb = nullptr, *vw = nullptr;
   float *fc_part = nullptr;      // [slabs][Gpad][256 | 384] partial sums of the policy Linear (sized for 2*FC_SPLITK slabs per column)
   int fc_G1 = 0, fc_s1 = FC_SPLITK, fc_s2 = FC_SPLITK;   // work decomposition chosen at load time (plan_fc)
-  int fc_layout = 0;                 // the loaded blob's weight fragment order: 0 -> k_fc, 1 -> k_fc16, 2 -> k_fcw (256 x 384 block tiles)
+  int fc_layout = 1;                 // the loaded blob's policy-Linear layout: 1 -> k_fc16 (256 x 256 block tiles), 2 -> k_fcw (256 x 384)
   int fc_gw = 256;                   // columns per column group (block tile width): 256, or FCW_COLS for layout 2
   unsigned char *towerW = nullptr;   // k_tower's weight stream: [(2*nblocks + 2) * 9 taps][32 KiB] in LDS-image order (F == 128)
   unsigned char *stemW = nullptr;    // [9 taps][8 KiB], same order
   float *towerB = nullptr;           // [2*nblocks + 2][256] (128 used)
   bool use_tower = false;            // hidden == 128: k_tower
-  int tower_waves = getenv("FPC_TOWER_WAVES") ? atoi(getenv("FPC_TOWER_WAVES")) : 8;   // developer knob (A/B): 4 = one wave per SIMD
-  bool use_tower256 = false;         // hidden == 256 megakernel: k_towerw<256> (any board size) ...
-  bool tower256_v1 = false;          // ... or, FPC_TOWER256_V1=1 on the 14x14 board, round 2's k_tower256
+  int tower_waves = 8;               // developer knob FPC_TOWER_WAVES (A/B): 4 = one wave per SIMD
+  bool tower_compact = true;         // 14x14: k_towerc (k_tower's skeleton on the compact image, 13 row tiles); developer knob FPC_TOWER_COMPACT=0: k_tower
   int towerw_rows = 1;               // developer knob FPC_TOWERW_ROWS=2: hidden 256 on two wave rows x four (A/B)
   bool use_towerw = false;           // k_towerw runs the tower (hidden 256; hidden 128 on every board but 14x14)
   void (*mark_fn)(void *, int) = nullptr;   // stage-timing hook of the engine (tag 2 = policy Linear starts)
   void *mark_ctx = nullptr;
   float vb = 0.f;
   // dynamic-LDS opt-ins (hipFuncSetAttribute) already made for this engine's device
-  bool attr_conv[2][3] = {{false, false, false}, {false, false, false}}, attr_tower[2] = {false, false}, attr_tower256[2] = {false, false}, attr_towerw[2] = {false, false}, attr_fc[2] = {false, false}, attr_gemv = false;
+  bool attr_conv[2][3] = {{false, false, false}, {false, false, false}}, attr_tower[2] = {false, false}, attr_towerw[2] = {false, false}, attr_fc[2] = {false, false}, attr_gemv = false;
 
   template <class T>
   int dmalloc(T **p, size_t count, std::string *err) {
@@ -480,7 +475,7 @@ struct NN {
   const fpc_board *in_boards = nullptr;
   const int *in_leaf_slot = nullptr, *in_leaf_turn = nullptr;
   int in_board_stride = 0;
-  bool takes_boards() const { return use_tower || use_tower256 || use_towerw; }
+  bool takes_boards() const { return use_tower || use_towerw; }
   void set_board_input(const fpc_board *b, int stride, const int *slot, const int *turn) { in_boards = b; in_board_stride = stride; in_leaf_slot = slot; in_leaf_turn = turn; }
   uint16_t one16() const { return dtype ? 0x3C00 : 0x3F80; }
   float *logits() { return d_logits; }
@@ -532,11 +527,10 @@ struct NN {
     if (nbytes < sizeof(BlobHeader)) { *err = "weight blob too small"; return FPC_EWEIGHTS; }
     BlobHeader h;
     memcpy(&h, blob, sizeof(h));
-    if (memcmp(h.magic, "FPCW", 4) || (h.version != 2 && h.version != 3)) { *err = "bad weight blob magic/version (this engine reads versions 2 and 3)"; return FPC_EWEIGHTS; }
-    if (h.version == 2 && h.fc_layout != 0) { *err = "weight blob version 2 carries a policy-Linear layout word (version 3 does)"; return FPC_EWEIGHTS; }
+    if (memcmp(h.magic, "FPCW", 4) || h.version != 3) { *err = "bad weight blob magic/version (this engine reads version 3; version 2 carried the retired 32x32x16 policy-Linear order: export again)"; return FPC_EWEIGHTS; }
     if (h.R != dc.R || h.A_ch != dc.A_ch) { *err = "weight blob is for a different board size"; return FPC_EWEIGHTS; }
     if (h.dtype != dtype) { *err = "weight blob dtype differs from engine nn_dtype"; return FPC_EWEIGHTS; }
-    if (h.fc_layout < 0 || h.fc_layout > 2) { *err = "unknown policy-Linear weight layout in weight blob"; return FPC_EWEIGHTS; }
+    if (h.fc_layout < 1 || h.fc_layout > 2) { *err = "unknown policy-Linear weight layout in weight blob (1 = k_fc16, 2 = k_fcw)"; return FPC_EWEIGHTS; }
     if (h.F % 64 || h.F < 64 || h.F > 512 || h.nblocks < 0 || h.Np % (h.fc_layout == 2 ? FCW_COLS : 256) || h.Kp % 512 || h.Kp < 1024 || h.Np < dc.A || h.Kp < dc.A) {
       *err = "unsupported network shape in weight blob (hidden must be a multiple of 64, Np of 256 -- 384 for fc_layout 2 --, Kp of 512)";
       return FPC_EWEIGHTS;
@@ -595,21 +589,23 @@ struct NN {
     if ((rc = dmalloc(&d_logits, (size_t)Gmax * dc.A, err))) return rc;
     if ((rc = dmalloc(&d_stats, (size_t)Gmax * SM_MAXCH * SM_REC, err))) return rc;
     if ((rc = dmalloc(&d_value, (size_t)Gmax, err))) return rc;
-    use_tower = use_tower256 = use_towerw = tower256_v1 = false;
-    const bool no_tower = getenv("FPC_NO_TOWER") != nullptr;
-    auto knob = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
+    use_tower = use_towerw = false;
+    // Developer knobs (same-box A/Bs, bit-identity tests): consulted ONLY when FPC_DEV_KNOBS=1 is in the environment, so a
+    // product run never changes kernels because of a stray variable.
+    const bool dev = getenv("FPC_DEV_KNOBS") && atoi(getenv("FPC_DEV_KNOBS")) != 0;
+    auto knob = [dev](const char *name, int dflt) { const char *v = dev ? getenv(name) : nullptr; return v ? atoi(v) : dflt; };
+    const bool no_tower = knob("FPC_NO_TOWER", 0) != 0;
+    tower_waves = knob("FPC_TOWER_WAVES", 8);
+    tower_compact = knob("FPC_TOWER_COMPACT", 1) != 0;
     // Which megakernel runs the tower (one launch, activations LDS-resident; everything else: k_conv3x3 per layer):
-    //   hidden 256: k_towerw (two waves per SIMD, weights L2 -> registers; any board size).  Developer knob for same-box
-    //               A/Bs: FPC_TOWER256_V1=1 = round 2's k_tower256 (one wave per SIMD, LDS weight ring; 14x14 only).
+    //   hidden 256: k_towerw (two waves per SIMD, weights L2 -> registers; any board size).
     //   hidden 128: 14x14: k_tower (LDS-DMA weight ring, loader / staggered wave roles; its grid rows ARE the 16-position row
     //               tiles there: 0.257 ms per 256 leaves against k_towerw's 0.274); every other board size: k_towerw, whose
     //               compact image computes ceil(R^2 / 16) row tiles where k_tower's bordered grid needs 6 / 10 / 14
     //               (8x8: 0.122 against 0.147 ms, 10x10: 0.171 / 0.208, 13x13: 0.242 / 0.285).  Developer knob
     //               FPC_TOWERW=0 / 1 forces k_tower / k_towerw.
     if (F == 256 && !no_tower) {
-      use_tower256 = true;
-      tower256_v1 = knob("FPC_TOWER256_V1", 0) != 0 && dc.R == 14;
-      use_towerw = !tower256_v1;
+      use_towerw = true;
       towerw_rows = knob("FPC_TOWERW_ROWS", 1);
     } else if (F == 128 && !no_tower) {
       const int kw = knob("FPC_TOWERW", -1);          // -1: by board size
@@ -649,20 +645,6 @@ struct NN {
       prep(pconv, 2 * nblocks + 1);
       hipLaunchKernelGGL(k_tower_prep, dim3((9 * 128 * 4 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)stem.w, stemW, 9, 32);
       if (hipStreamSynchronize(stream) != hipSuccess) { *err = "k_tower_prep failed"; return FPC_ENODEVICE; }
-    } else if (tower256_v1) {
-      // k_tower256 streams one 16 KiB slab per k-step ([256 cout][32 cin], LDS-image order, fpc_tower256.h)
-      if ((rc = dmalloc(&towerW, (size_t)layers * 9 * T2_KS * T2_SLAB, err)) || (rc = dmalloc(&stemW, (size_t)9 * T2_SLAB, err)) ||
-          (rc = dmalloc(&towerB, (size_t)layers * 256, err))) return rc;
-      auto prep = [&](const ConvW &cw, int layer) {
-        hipLaunchKernelGGL(k_tower256_prep, dim3((9 * T2_KS * 256 * 4 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)cw.w,
-                           towerW + (size_t)layer * 9 * T2_KS * T2_SLAB, 9, cw.cout_pad);
-        (void)hipMemcpyAsync(towerB + (size_t)layer * 256, cw.b, (size_t)std::min(cw.cout_pad, 256) * 4, hipMemcpyDeviceToDevice, stream);
-      };
-      for (int i = 0; i < nblocks; ++i) { prep(c1[i], 2 * i); prep(c2[i], 2 * i + 1); }
-      prep(vconv, 2 * nblocks);
-      prep(pconv, 2 * nblocks + 1);
-      hipLaunchKernelGGL(k_tower256_prep_stem, dim3((9 * 256 * 4 + 255) / 256), dim3(256), 0, stream, (const uint16_t *)stem.w, stemW);
-      if (hipStreamSynchronize(stream) != hipSuccess) { *err = "k_tower256_prep failed"; return FPC_ENODEVICE; }
     }
     loaded = true;
     return 0;
@@ -708,7 +690,7 @@ struct NN {
       return launch_conv<DT>(g, M, err);
     };
     int cur = 0;
-    if (use_tower || use_tower256 || use_towerw) {
+    if (use_tower || use_towerw) {
       TowerArgs t{};
       t.boards = in_boards; t.leaf_slot = in_leaf_slot; t.leaf_turn = in_leaf_turn; t.board_stride = in_board_stride; t.one16 = one16();
       in_boards = nullptr;
@@ -733,6 +715,7 @@ struct NN {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 3, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 5, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower<DT, 7, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_towerc<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS);
         attr = true;
       }
       if (use_towerw) {
@@ -769,17 +752,15 @@ struct NN {
 #undef FPC_TWW_GO1
 #undef FPC_TWW_GOS
 #undef FPC_TWW_GO
-      } else if (tower256_v1) {
-        bool &a256 = attr_tower256[DT];
-        if (!a256) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tower256<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS); a256 = true; }
-        hipLaunchKernelGGL((k_tower256<DT>), dim3(n), dim3(TW_THREADS), T2_LDS, stream, t);
       } else if (mt == 3 && tower_waves == 8) hipLaunchKernelGGL((k_tower<DT, 3, false, 8>), dim3(n), dim3(512), TW_LDS, stream, t);
       else if (mt == 3) hipLaunchKernelGGL((k_tower<DT, 3, false, 4>), dim3(n), dim3(256), TW_LDS, stream, t);
       else if (mt == 5 && tower_waves == 8) hipLaunchKernelGGL((k_tower<DT, 5, false, 8>), dim3(n), dim3(512), TW_LDS, stream, t);
       else if (mt == 5) hipLaunchKernelGGL((k_tower<DT, 5, false, 4>), dim3(n), dim3(256), TW_LDS, stream, t);
       else if (P != 16 && tower_waves == 8) hipLaunchKernelGGL((k_tower<DT, 7, false, 8>), dim3(n), dim3(512), TW_LDS, stream, t);
       else if (P != 16) hipLaunchKernelGGL((k_tower<DT, 7, false, 4>), dim3(n), dim3(256), TW_LDS, stream, t);
-      // 14x14 (grid pitch == tile height): two waves per SIMD, 7 x 2 tiles each
+      // 14x14: the compact image (13 row tiles: loaders 6, staggered half 7) ...
+      else if (tower_waves == 8 && tower_compact && dc.R == 14) hipLaunchKernelGGL((k_towerc<DT>), dim3(n), dim3(512), TW_LDS, stream, t);
+      // ... or the bordered grid (grid pitch == tile height): two waves per SIMD, 7 x 2 tiles each
       else if (tower_waves == 8) hipLaunchKernelGGL((k_tower<DT, 7, true, 8>), dim3(n), dim3(512), TW_LDS, stream, t);
       else hipLaunchKernelGGL((k_tower<DT, 7, true, 4>), dim3(n), dim3(256), TW_LDS, stream, t);
       const hipError_t le = hipGetLastError();
@@ -796,7 +777,7 @@ struct NN {
       }
 #endif
     } else if ((rc = conv(stem, in16, 32, nullptr, act[0], F, F, 0))) return rc;
-    const bool fused = use_tower || use_tower256 || use_towerw;
+    const bool fused = use_tower || use_towerw;
     for (int i = 0; i < nblocks && !fused; ++i) {
       const int t1 = (cur + 1) % 3, t2 = (cur + 2) % 3;
       if ((rc = conv(c1[i], act[cur], F, nullptr, act[t1], F, F, 0))) return rc;
@@ -816,14 +797,12 @@ struct NN {
       const int blocks = fc_G1 * fc_s1 + (Np / fc_gw - fc_G1) * fc_s2;
       bool &fattr = attr_fc[DT];
       if (!fattr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fc<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fc16<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fcw<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, FCW_LDS);
         fattr = true;
       }
       if (fc_layout == 2) hipLaunchKernelGGL((k_fcw<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), FCW_LDS, stream, f);
-      else if (fc_layout == 1) hipLaunchKernelGGL((k_fc16<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), FC_LDS, stream, f);
-      else hipLaunchKernelGGL((k_fc<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), FC_LDS, stream, f);
+      else hipLaunchKernelGGL((k_fc16<DT>), dim3(blocks, mtiles), dim3(FC_THREADS), FC_LDS, stream, f);
       hipLaunchKernelGGL(k_fc_reduce, dim3((dc.A / 4 + 255) / 256, n), dim3(256), 0, stream, (const float *)fc_part, (const float *)fcb,
                          fc_G1, fc_s1, fc_s2, fc_gw, Gpad, dc.A, n, skip_dense ? (float *)nullptr : logits_out, d_stats);
       const hipError_t le = hipGetLastError();
@@ -857,9 +836,8 @@ struct NN {
     int rc;
     if ((rc = dmalloc(&fcw2, (size_t)Np * Kp, err)) || (rc = dmalloc(&d_ll, (size_t)Gmax * FPC_MAX_MOVES, err))) return rc;
     const long chunks = (long)Np * (Kp / 8);
-    const int order = fc_layout == 0 ? 0 : 1;      // layout 2 is layout 1's fragment order over a wider Np
-    if (dtype) hipLaunchKernelGGL((k_fc_unfrag<1>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)fcw, fcw2, Np, Kp, order);
-    else hipLaunchKernelGGL((k_fc_unfrag<0>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)fcw, fcw2, Np, Kp, order);
+    if (dtype) hipLaunchKernelGGL((k_fc_unfrag<1>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)fcw, fcw2, Np, Kp);   // layouts 1 and 2: one fragment order
+    else hipLaunchKernelGGL((k_fc_unfrag<0>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)fcw, fcw2, Np, Kp);
     if (hipGetLastError() != hipSuccess) { *err = "k_fc_unfrag launch failed"; return FPC_ENODEVICE; }
     return 0;
   }

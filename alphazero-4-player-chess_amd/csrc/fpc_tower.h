@@ -222,8 +222,18 @@ __device__ __forceinline__ void tw_dma_256(const unsigned char *gsrc_uniform, ui
 // serial with the MFMA stream.  Every output element sees the same MFMAs on the same operands in
 // the same order in both forms, so the logits are bit-identical.
 // LOAD: weight-DMA pieces this wave carries per k-step (0, 1 or 2), i.e. 4 * LOAD KiB of every tap
-template <int DT, int MT, bool FAST, int NW, int LOAD>
+// CMP (round 5; 14x14 only, NW = 8 with loader / stagger roles): the COMPACT image of k_towerw in this kernel's skeleton --
+// image row 16 + p is square p = 14 i + j of the board, no border columns, 16 zero rows in front and 28 behind.  A tap is
+// the row shift 14 dy + dx; where j + dx leaves the board (column 0 under dx = -1, column 13 under dx = +1) the lane reads
+// a zero row of the same LDS bank instead (one v_cndmask per row tile and tap on a compile-time lane mask).  13 row tiles
+// of 16 squares instead of 14 grid rows: the loader half (waves 0-3, which also carries the weight DMA) owns tiles 0..5,
+// the staggered half tiles 6..12 -- 7 % fewer MFMAs and fragment reads per layer, same MFMAs per output element in the
+// same order (bit-identical logits; the value head sums the same terms in another order).
+template <int DT, int MT, bool FAST, int NW, int LOAD, bool CMP = false>
 __device__ __forceinline__ void tw_body(const TowerArgs &g) {
+  static_assert(!CMP || (!FAST && NW == 8 && TW_LOADERS == 1 && MT == (LOAD == 2 ? 6 : 7)), "compact form: 8 waves, tiles 6 + 7");
+  constexpr int CR = 14, CZ = 16;                   // CMP: board side, zero rows in front of square 0
+  constexpr int TB0 = LOAD == 2 ? 0 : 6;           // CMP: first row tile of this wave half
   constexpr int NT = NW * 64;                      // threads
   constexpr int WN = NW / 2;                       // waves along the output channels
   constexpr int CT = 8 / WN;                       // column tiles (16 channels) per wave: 4 or 2
@@ -254,14 +264,31 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
   }
 
   // ---- per-lane geometry -------------------------------------------------------------------------
-  const int rbase = (g.T0 + wm * MT) * 16 + li;       // grid position (image row) of this lane in its first row tile
+  const int rbase = CMP ? CZ + TB0 * 16 + li : (g.T0 + wm * MT) * 16 + li;       // grid position (image row) of this lane in its first row tile
   uint32_t inmask = 0;                                // bit mt: the lane's position in row tile mt is an interior square
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int r = rbase + 16 * mt;
-    const int pi = r / P, pj = r - pi * P;
-    if (r < g.PP && pi >= 1 && pi <= g.R && pj >= 1 && pj <= g.R) inmask |= 1u << mt;
+    if (CMP) {
+      if (r - CZ < CR * CR) inmask |= 1u << mt;       // only the board's last tile (196 = 12 * 16 + 4) has lanes past the last square
+    } else {
+      const int pi = r / P, pj = r - pi * P;
+      if (r < g.PP && pi >= 1 && pi <= g.R && pj >= 1 && pj <= g.R) inmask |= 1u << mt;
+    }
   }
+  // CMP: the lanes of row tile mt whose square sits in board column 0 (dx = -1 reads off the board) / 13 (dx = +1): compile-time
+  auto colmask = [](int mt, int dx) -> uint64_t {
+    uint32_t m16 = 0;
+    for (int i = 0; i < 16; ++i)
+      if (dx != 0 && ((TB0 + mt) * 16 + i) % CR == (dx < 0 ? 0 : CR - 1)) m16 |= 1u << i;
+    const uint32_t m32 = m16 * 0x10001u;
+    return ((uint64_t)m32 << 32) | m32;
+  };
+  auto lane_select = [](uint32_t a, uint32_t b, uint64_t m) -> uint32_t {   // m's lanes: b; the others: a
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+    return r;
+  };
   const int bq = (lq >> 1) * 256 + (lq & 1) * 128;                 // chunk-within-k-step part of a fragment address
   const int apart = (li >> 3) * 2048 + (li & 7) * 16 + bq;         // weight fragment: row li of a 16-row tile (CH = 16)
   const int apart_s = (li >> 3) * 512 + (li & 7) * 16 + bq;        // same for the stem's 4-chunk rows
@@ -272,7 +299,7 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
   // ---- zero the image, build the stem's input image, fetch the stem's weights -----------------------
   for (int c = tid; c < (TW_IMG0 + TW_IMG) / 16; c += NT) reinterpret_cast<t_u32x4 *>(smem)[c] = t_u32x4{0u, 0u, 0u, 0u};
   unsigned char *const enc = smem + TW_ENC;
-  const int enc_bytes = ((NR + 7) >> 3) * 512;
+  const int enc_bytes = CMP ? 240 * 64 : ((NR + 7) >> 3) * 512;
   for (int c = tid; c < enc_bytes / 16; c += NT) reinterpret_cast<t_u32x4 *>(enc)[c] = t_u32x4{0u, 0u, 0u, 0u};
   {  // stem weights: 72 KiB by plain 16-byte copies (once per launch)
     const t_u32x4 *src = reinterpret_cast<const t_u32x4 *>(g.Wstem);
@@ -291,13 +318,20 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
     // GetEncodedStates: plane = 6*((colour - turn) & 3) + type - 1, -1 wrapping to 23 (Q7); the whole
     // batch is rotated by the turn of the first live leaf (Q6) -- unless the non-strict rules say otherwise
     if (g.rules & FPC_RULES_ROTATION) rot_k = lboard->turn;
-    for (int r = tid; r < g.PP; r += NT) {
-      const int pi = r / P, pj = r - pi * P;
+    for (int r = tid; r < (CMP ? CR * CR : g.PP); r += NT) {
+      const int pi = CMP ? r / CR + 1 : r / P, pj = CMP ? r % CR + 1 : r - pi * P;      // 1-based square of grid position / square r
       if (pi < 1 || pi > g.R || pj < 1 || pj > g.R) continue;
       const uint8_t p = lboard->sq[rot90_src(g.R, rot_k, pi - 1, pj - 1)];
       if (!present(p)) continue;
       const int plane = piece_plane(p, lboard->turn, g.rules);
-      *reinterpret_cast<uint16_t *>(enc + tw_lay(4, r, plane >> 3) + (plane & 7) * 2) = g.one16;
+      *reinterpret_cast<uint16_t *>(enc + tw_lay(4, CMP ? CZ + r : r, plane >> 3) + (plane & 7) * 2) = g.one16;
+    }
+  } else if (CMP) {
+    const uint16_t *src = g.in16 + (size_t)game * g.PP * 32;      // bordered grid [(R + 2)^2][32]
+    for (int c = tid; c < CR * CR * 4; c += NT) {
+      const int q = c >> 2, j = c & 3;
+      *reinterpret_cast<t_u32x4 *>(enc + tw_lay(4, CZ + q, j)) =
+          *reinterpret_cast<const t_u32x4 *>(src + ((size_t)(q / CR + 1) * P + q % CR + 1) * 32 + j * 8);
     }
   } else {
     const uint16_t *src = g.in16 + (size_t)game * g.PP * 32;
@@ -324,14 +358,14 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
   // ---- stem: conv3x3(24 -> 128) on the 32-channel input image, one 32-deep k-step per tap -----------
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
-    const int shift = (tap / 3 - 1) * P + (tap % 3 - 1);
+    const int shift = (tap / 3 - 1) * (CMP ? CR : P) + (tap % 3 - 1);
     t_u32x4 fa[CT], fb[MT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
       fa[ct] = *reinterpret_cast<const t_u32x4 *>(ring + tap * TW_STEM_TAP + (cb64 + ct * 16) * 64 + apart_s);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int r = brow(mt, shift);
+      const int r = CMP ? (int)lane_select((uint32_t)(rbase + 16 * mt + shift), (uint32_t)((rbase + shift) & 7), colmask(mt, tap % 3 - 1)) : brow(mt, shift);
       fb[mt] = *reinterpret_cast<const t_u32x4 *>(enc + (r >> 3) * 512 + (r & 7) * 16 + bq);
     }
 #pragma unroll
@@ -434,6 +468,16 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
       int rl = r + 16 * (MT - 1);
       rl = rl >= NR ? rl - NR : rl;
       blast = img + (rl >> 3) * 2048 + (rl & 7) * 16 + bq;
+    } else if (CMP) {
+      const int dx = tap % 3 - 1;                    // wave-uniform
+      const int r = rbase + (tap / 3 - 1) * CR + dx; // >= 16 - 15
+      const uint32_t zoff = (r & 7) * 16 + bq;       // the zero row with this row's low three bits: same LDS bank
+      const uint32_t b0 = (r >> 3) * 2048 + zoff;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const uint64_t m = dx < 0 ? colmask(mt, -1) : dx > 0 ? colmask(mt, 1) : 0ull;
+        boff[mt] = (int)lane_select(b0 + mt * 4096, zoff, m);
+      }
     } else {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -563,7 +607,7 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
       const int r = rbase + 16 * mt;
       const int pi = r / P, pj = r - pi * P;
       const bool in = ((inmask >> mt) & 1u) && (NW == 4 || vactive);
-      const int qp = in ? (pi - 1) * g.R + (pj - 1) : 0;
+      const int qp = !in ? 0 : CMP ? r - CZ : (pi - 1) * g.R + (pj - 1);
       const t_f32x4 w4 = *reinterpret_cast<const t_f32x4 *>(g.vw + qp * 32 + cb16 + 4 * lq);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -581,12 +625,16 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
   // ---- heads: policy-conv rows -> Linear input (position-major), value -> tanh ---------------------------
   {
     const int cpr = g.A_ch / 8;                     // 16-byte chunks per position
-    for (int c = tid; c < g.PP * 16; c += NT) {
-      const int r = c >> 4, j = c & 15;
+    for (int c = tid; c < (CMP ? CR * CR : g.PP) * 16; c += NT) {
+      const int j = c & 15;
       if (j >= cpr) continue;
-      const int pi = r / P, pj = r - pi * P;
-      if (pi < 1 || pi > g.R || pj < 1 || pj > g.R) continue;
-      const int q = (pi - 1) * g.R + (pj - 1);
+      int r = c >> 4, q = r;
+      if (CMP) r += CZ;
+      else {
+        const int pi = r / P, pj = r - pi * P;
+        if (pi < 1 || pi > g.R || pj < 1 || pj > g.R) continue;
+        q = (pi - 1) * g.R + (pj - 1);
+      }
       *reinterpret_cast<t_u32x4 *>(g.xfc + (size_t)game * g.Kp + (size_t)q * g.A_ch + j * 8) =
           *reinterpret_cast<const t_u32x4 *>(img + tw_lay(16, r, j));
     }
@@ -609,6 +657,13 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tower(TowerArgs g) {
   } else {
     tw_body<DT, MT, FAST, NW, NW == 4 ? 2 : 1>(g);
   }
+}
+
+// the compact form at 14x14 (CMP): loaders = row tiles 0..5, staggered half = row tiles 6..12
+template <int DT>
+__global__ void __launch_bounds__(512, 2) k_towerc(TowerArgs g) {
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) tw_body<DT, 6, false, 8, 2, true>(g);
+  else tw_body<DT, 7, false, 8, 0, true>(g);
 }
 
 // weights [taps][128 rows][cin] 16-bit row-major -> per tap the LDS image (tw_lay with cin/8 chunks per row)

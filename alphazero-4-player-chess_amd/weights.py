@@ -43,7 +43,8 @@ def _conv_section(w, b, cin_pad, cout_pad, dtype):
 
 # Fragment order / block tile of the policy Linear: 2 = 16x16x32 fragments over 384-column groups (k_fcw: 256 x 384 block
 # tiles, one round of blocks; the default where its one-round K-split exists: the 14x14 board), 1 = the same fragment order
-# over 256-column groups (k_fc16, the default elsewhere), 0 = 32x32x16 (k_fc).  FPC_FC_LAYOUT forces one.
+# over 256-column groups (k_fc16, the default elsewhere).  FPC_FC_LAYOUT forces one.  (0, the 32x32x16 order of k_fc, was
+# retired in round 5 together with blob version 2.)
 FC_LAYOUT = int(os.environ["FPC_FC_LAYOUT"]) if "FPC_FC_LAYOUT" in os.environ else None
 
 
@@ -85,14 +86,11 @@ def export_weights(model, dtype=0, fc_layout=None):
     fwp = torch.zeros(Np, Kp, dtype=t16)
     fwp[:A, :A] = fw.to(t16)
     del fw
-    if fc_layout == 0:
-        # MFMA fragment order of k_fc (32x32x16): [kstep16][n_tile32][lane = 32*h + r][8],
-        # element (ks, nt, h, r, e) = W'[nt*32 + r][ks*16 + h*8 + e]
-        wf = fwp.view(Np // 32, 32, Kp // 16, 2, 8).permute(2, 0, 3, 1, 4).contiguous()
-    else:
-        # MFMA fragment order of k_fc16 / k_fcw (16x16x32): [kstep32][n_tile16][lane = 16*q + c][8],
-        # element (ks, nt, q, c, e) = W'[nt*16 + c][ks*32 + q*8 + e]
-        wf = fwp.view(Np // 16, 16, Kp // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
+    if fc_layout not in (1, 2):
+        raise ValueError("fc_layout must be 1 (k_fc16) or 2 (k_fcw); 0 (k_fc) was retired")
+    # MFMA fragment order of k_fc16 / k_fcw (16x16x32): [kstep32][n_tile16][lane = 16*q + c][8],
+    # element (ks, nt, q, c, e) = W'[nt*16 + c][ks*32 + q*8 + e]
+    wf = fwp.view(Np // 16, 16, Kp // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
     del fwp
     secs.append(wf.view(torch.int16).numpy().tobytes())
     del wf
@@ -104,10 +102,9 @@ def export_weights(model, dtype=0, fc_layout=None):
     vw[:, :24] = _cpu(vfc.weight).view(24, RR).t()
     secs.append(vw.numpy().astype(np.float32).tobytes())
     secs.append(struct.pack("<f", float(_cpu(vfc.bias).item())))
-    # version 2: the policy Linear in k_fc's 32x32x16 fragment order (the header word that now holds fc_layout was
-    # padding then); version 3: fc_layout says which order -- an engine built before that word existed reads a
-    # layout-1 blob as layout 0, so such blobs carry a version it refuses
-    version = 2 if fc_layout == 0 else 3
+    # version 3: the header word fc_layout names the policy Linear's layout (version 2, rounds 1-2: k_fc's 32x32x16
+    # order without that word; an engine of that time refuses version 3, this engine refuses version 2)
+    version = 3
     out = bytearray(struct.pack("<4s9i24x", b"FPCW", version, R, F, nblocks, dtype, A_ch, Np, Kp, fc_layout))
     assert len(out) == 64
     for s in secs:

@@ -462,7 +462,7 @@ def main():
     # algorithmic bytes of the policy Linear inside the fused search: the 16-bit weight matrix read once + X read once.
     # (The dense f32 logits matrix -- 4 G A bytes -- is no longer written there: k_fc_reduce leaves the softmax records,
     # the expansion reads the split-K slabs at the legal moves.  FPC_DENSE_LOGITS=1 brings the write back.)
-    fc_bytes = 2.0 * Np * Kp + 2.0 * G * Kp + (4.0 * G * A if os.environ.get("FPC_DENSE_LOGITS") else 0.0)
+    fc_bytes = 2.0 * Np * Kp + 2.0 * G * Kp + (4.0 * G * A if os.environ.get("FPC_DENSE_LOGITS") and os.environ.get("FPC_DEV_KNOBS") == "1" else 0.0)
     pmc = {}
     try:     # HBM bytes per launch measured with rocprofv3 --pmc (tools/pmc_nn.sh), committed under profiles/
         pmc = json.load(open(os.path.join(HERE, "profiles", "pmc_summary.json")))
@@ -478,7 +478,6 @@ def main():
 
     shape_key = "r%d_b%d_h%d_g%d" % (R, Nb, F, G)
     tower_desc = {"k_tower": "k_tower (residual tower megakernel, hidden 128, LDS-resident activations)",
-                  "k_tower256": "k_tower256 (residual tower megakernel, hidden 256, one wave per SIMD, 2-slab LDS weight ring; developer knob)",
                   "k_towerw": "k_towerw (residual tower megakernel, hidden %d, two waves per SIMD, weights L2 -> registers, LDS-resident activations)" % F,
                   "k_conv3x3": "k_conv3x3 x %d launches (per-layer implicit GEMM, activations through L2) + k_value_tail" % (2 * Nb + 3)}.get(nn_kernel, nn_kernel)
     fc_kernels = [{0: "k_fc", 1: "k_fc16", 2: "k_fcw"}[weights.default_fc_layout(R)], "k_fc_reduce"]   # the Linear (by the weight layout exported) and its split-K reduce

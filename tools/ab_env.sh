@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of ONE library under different environment knobs in ONE gpurun call (same box, alternating), e.g.
 #   gpurun -- 'bash tools/ab_env.sh 3 FPC_TOWER_WAVES=4 FPC_TOWER_WAVES=8'
+export FPC_DEV_KNOBS=1      # the engine reads its developer knobs only with this set
 N=$1; shift
 for i in $(seq 1 $N); do
   for KV in "$@"; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FPC_DEV_KNOBS=1      # the engine reads its developer knobs only with this set
 # SQ counters of the network forward under two settings of an environment knob (separate --pmc passes, kernel trace only)
 #   gpurun -- 'bash tools/pmc_tower_ab.sh FPC_TOWER_WAVES 4 8'
 KNOB=$1; shift

@@ -3,6 +3,7 @@
 environment knob (e.g. FPC_TOWER_WAVES=4 vs 8: same MFMAs, same order, other wave decomposition).
     python3 tools/same_logits.py FPC_TOWER_WAVES 4 8 [board] [blocks] [hidden]"""
 import os, subprocess, sys
+os.environ["FPC_DEV_KNOBS"] = "1"      # the engine reads its developer knobs only with this set
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.path[:0] = [os.path.join(HERE, "alphazero-4-player-chess_amd"), HERE]

@@ -4,6 +4,7 @@ consecutive taps of k_tower, block 0, every wave -- s_memtime (100 MHz-independe
 relative to the earliest stamp.  FPC_TOWER_WAVES=4|8 picks the kernel form.
     FPC_ENGINE_LIB=$PWD/tools/var/lib_stamps.so python3 tools/tower_stamps.py"""
 import os, subprocess, sys
+os.environ["FPC_DEV_KNOBS"] = "1"      # the engine reads its developer knobs only with this set
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = "/tmp/tw_stamps.txt"
 env = dict(os.environ, FPC_TW_STAMPS_FILE=out)

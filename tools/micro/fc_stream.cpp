@@ -252,10 +252,10 @@ int main(int argc, char **argv) {
         }
       }
       CK(hipMemcpy(dwork, work.data(), work.size() * sizeof(Work), hipMemcpyHostToDevice));
-      for (int combo = 0; combo < 4; ++combo) {
-        const int mf = combo & 1, sl = combo >> 1;
+      for (int combo = 0; combo < 6; ++combo) {
+        const int mf = combo < 4 ? (combo & 1) : 1, sl = combo < 4 ? (combo >> 1) : 1, tiled = combo == 4, pitch0 = combo == 5;
         auto launch = [&]() {
-          if (mf) hipLaunchKernelGGL((k_stream<1, 1, 1>), dim3((unsigned)work.size()), dim3(256), LDS, 0, W, X, part, dwork, Kp + 64, sl, 0, 4, 1, 0, 0, 0, 0, wide);
+          if (mf) hipLaunchKernelGGL((k_stream<1, 1, 1>), dim3((unsigned)work.size()), dim3(256), LDS, 0, W, X, part, dwork, pitch0 ? Kp : Kp + 64, sl, tiled, 4, 1, 0, 0, 0, 0, wide);
           else hipLaunchKernelGGL((k_stream<1, 0, 1>), dim3((unsigned)work.size()), dim3(256), LDS, 0, W, X, part, dwork, Kp + 64, sl, 0, 4, 1, 0, 0, 0, 0, wide);
         };
         for (int r = 0; r < reps / 3 + 2; ++r) launch();
@@ -264,7 +264,7 @@ int main(int argc, char **argv) {
         for (int r = 0; r < reps; ++r) launch();
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-        printf("tile 256 x %d  blocks %zu | mfma %d slabs %d | %.1f us\n", wide ? 384 : 256, work.size(), mf, sl, ms * 1e3);
+        printf("tile 256 x %d  blocks %zu | mfma %d slabs %d X %s | %.1f us\n", wide ? 384 : 256, work.size(), mf, sl, tiled ? "tiled" : pitch0 ? "rows pitch Kp" : "rows pitch Kp+64", ms * 1e3);
         fflush(stdout);
       }
     }

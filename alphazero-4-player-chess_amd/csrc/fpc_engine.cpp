@@ -1095,7 +1095,7 @@ const char *fpc_nn_kernel(fpc_engine *e) {
   return "";
 #else
   if (!e || !e->nn.loaded) return "";
-  return e->nn.use_towerw ? "k_towerw" : e->nn.use_tower ? "k_tower" : "k_conv3x3";
+  return e->nn.use_towerw ? "k_towerw" : e->nn.use_tower ? (e->nn.tower_compact && e->nn.tower_waves == 8 && e->dc.R == 14 ? "k_towerc" : "k_tower") : "k_conv3x3";
 #endif
 }
 void *fpc_stream(fpc_engine *e) { return e ? (void *)e->stream : nullptr; }

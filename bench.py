@@ -115,6 +115,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-stage-timing", action="store_true", help="developer knob: no HIP events between the stages (what do they cost?)")
     ap.add_argument("--no-alt-policy-head", action="store_true", help="skip the extra legal-only-policy-head measurement")
     ap.add_argument("--no-dropin", action="store_true", help="skip the extra measurement through mcts.MCTS.search + the reference's play loop")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE over the network forward) behind the timed region; "
+                         "roofline.traffic then comes from the committed profiles/pmc_summary.json")
     ap.add_argument("--policy-head", choices=["full", "legal"], default="full",
                     help="full: whole policy Linear + full softmax (reference arithmetic, the headline); legal: opt-in legal-moves-only head")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
@@ -470,14 +473,30 @@ def main():
         pass
 
     def pmc_traffic(kernels, shape_key):
-        """counter HBM bytes per launch of exactly these kernels on exactly this network shape, or None:
-        profiles/pmc_summary.json is keyed by shape ("r14_b10_h128") since round 3"""
+        """counter HBM bytes per launch of exactly these kernels on exactly this network shape, or None: counted by this
+        run's own rocprofv3 --pmc child passes (live_traffic) when they succeeded, else from the committed
+        profiles/pmc_summary.json (keyed by shape since round 3)"""
+        if live is not None:
+            vals = [live.get(k) for k in kernels]
+            if vals and all(v is not None for v in vals):
+                return sum(vals)
         ent = pmc.get(shape_key, {})
         vals = [ent.get(k, {}).get("hbm_bytes") for k in kernels]
         return sum(vals) if vals and all(v is not None for v in vals) else None
 
+    def traffic_source(kernels):
+        if live is not None and all(live.get(k) is not None for k in kernels):
+            return ("counted in THIS run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two separate child passes, kernel trace only) over "
+                    "fpc_nn_forward of this shape on this box (tools/nn_only.py; FETCH_SIZE doubled per the guide's gfx950 correction); "
+                    "fpc_nn_forward writes the dense logits too: k_fc_reduce carries 4 G A bytes the fused search does not")
+        return "profiles/pmc_summary.json[%s] (rocprofv3 --pmc passes of an earlier run of this kernel and shape, committed; NOT counted in this run)" % shape_key
+
     shape_key = "r%d_b%d_h%d_g%d" % (R, Nb, F, G)
+    live = None
+    if world == 1 and not args.no_live_traffic and not under_profiler():
+        live = live_traffic(R, Nb, F, G, dt)          # {kernel: HBM bytes per launch} counted NOW on this box, or None
     tower_desc = {"k_tower": "k_tower (residual tower megakernel, hidden 128, LDS-resident activations)",
+                  "k_towerc": "k_towerc (residual tower megakernel, hidden 128, LDS-resident activations on the compact 14x14 image: 13 row tiles, LDS-DMA weight ring)",
                   "k_towerw": "k_towerw (residual tower megakernel, hidden %d, two waves per SIMD, weights L2 -> registers, LDS-resident activations)" % F,
                   "k_conv3x3": "k_conv3x3 x %d launches (per-layer implicit GEMM, activations through L2) + k_value_tail" % (2 * Nb + 3)}.get(nn_kernel, nn_kernel)
     fc_kernels = [{0: "k_fc", 1: "k_fc16", 2: "k_fcw"}[weights.default_fc_layout(R)], "k_fc_reduce"]   # the Linear (by the weight layout exported) and its split-K reduce
@@ -495,7 +514,7 @@ def main():
         # dominant kernel: the residual tower (stem + 2*Nb residual convs + both head convs), one launch per network forward
         "roofline": {"bound": "mfma", "achieved": ach_tower, "peak": peak, "unit": "TFLOP/s", "frac": ach_tower / peak,
                      "traffic": pmc_traffic([nn_kernel], shape_key),
-                     "traffic_source": "profiles/pmc_summary.json[%s] (rocprofv3 --pmc passes of an earlier run of this kernel and shape, committed; NOT counted in this run)" % shape_key,
+                     "traffic_source": traffic_source([nn_kernel]),
                      "kernel": tower_desc,
                      "flops_per_launch": flops_tower, "ms_per_launch": tower_ms},
         # the policy Linear at M = 256: 255 FLOP per weight byte, below the 312 FLOP/B ridge -> HBM-bound.
@@ -503,7 +522,7 @@ def main():
         "roofline_policy_linear": {"bound": "hbm", "achieved": fc_bytes / (fc_ms * 1e-3) / 1e9 if fc_ms > 0 else 0.0, "peak": PEAK_HBM_GBS,
                                    "unit": "GB/s", "frac": (fc_bytes / (fc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if fc_ms > 0 else 0.0,
                                    "traffic": pmc_traffic(fc_kernels, shape_key),
-                                   "traffic_source": "profiles/pmc_summary.json[%s] (committed PMC passes, not counted in this run)" % shape_key,
+                                   "traffic_source": traffic_source(fc_kernels),
                                    "kernel": " + ".join(fc_kernels) + " (weight-streaming Linear, %.2f GB of 16-bit weights per launch)" % (2.0 * Np * Kp / 1e9),
                                    "bytes_per_launch": fc_bytes, "flops_per_launch": flops_fc, "ms_per_launch": fc_ms,
                                    "mfma_TFLOPs": ach_fc},
@@ -659,6 +678,44 @@ def float_parity(R, blocks, hidden, INV):
     return out
 
 
+def live_traffic(R, blocks, hidden, G, dt):
+    """HBM bytes per launch of the network forward's kernels, counted now: two child runs of tools/nn_only.py under
+    `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE, then WRITE_SIZE: separate passes, no other trace domain, as
+    MI355X_MICROARCH.md prescribes; this process only starts them and reads their CSVs).  {kernel base name: bytes}, or
+    None if rocprofv3 is missing or a pass fails (roofline.traffic then falls back to the committed summary)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or R != 14 or G != 256:
+        return None                                   # tools/nn_only.py drives the 14x14, 256-row forward
+    tmp = tempfile.mkdtemp(prefix="fpc_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", FPC_NN_BLOCKS=str(blocks), FPC_NN_HIDDEN=str(hidden), FPC_NN_DTYPE=str(dt))
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
+                                sys.executable, os.path.join(HERE, "tools", "nn_only.py"), "3"],
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            fs = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+            if r.returncode != 0 or not fs:
+                return None
+            agg = collections.defaultdict(list)
+            for row in csv.DictReader(open(fs[0])):
+                if row["Counter_Name"] == counter:
+                    agg[row["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]].append(float(row["Counter_Value"]))
+            vals[counter] = {k: sum(v) / len(v) for k, v in agg.items()}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {k: (2.0 * vals["FETCH_SIZE"][k] + vals["WRITE_SIZE"].get(k, 0.0)) * 1024.0 for k in vals["FETCH_SIZE"]}
+
+
 def under_profiler():
     """True when rocprofv3 / rocprofiler-sdk is wrapped around this process (its tool library is preloaded or configured)"""
     if any(k.startswith(("ROCPROF", "ROCPROFILER_", "ROCP_")) for k in os.environ):
@@ -709,7 +766,7 @@ def cpu_baseline(R, INV, model, args):
         dt = time.perf_counter() - t0
         return sum(r["sims_done"] for r in res) / dt, dt
 
-    Gc, sc = args.games, 8            # ~10-20 s of CPU work on the GPU box's 16 host cores
+    Gc, sc = args.games, 24           # ~12 s of CPU work on the GPU box's 16 host cores (8 sims took 4.0 s)
     v, dt = run(Gc, sc)
     out = {"value": v, "unit": "sims/s", "cores": cores, "kind": "port",
            "sample": "%d games x %d sims from the start position (the workload's batch shape), oracle tree + PyTorch-CPU fp32 ResNet(%d,%d), %.1f s"

@@ -256,8 +256,8 @@ int fpc_stats_get(fpc_engine *e, fpc_stats *out);
 int fpc_stats_reset(fpc_engine *e);
 int fpc_set_timing(fpc_engine *e, int enabled);  /* HIP events around each stage (adds syncs) */
 const char *fpc_nn_kernel(fpc_engine *e);        /* name of the kernel that runs the residual tower for the loaded weights:
-                                                  * "k_towerw" (hidden 256; hidden 128 off the 14x14 board), "k_tower" (hidden 128, 14x14),
-                                                  * "k_tower256" (developer knob), "k_conv3x3" (per layer), "" before fpc_load_weights */
+                                                  * "k_towerw" (hidden 256; hidden 128 off the 14x14 board), "k_towerc" (hidden 128, 14x14: k_tower's
+                                                  * skeleton on the compact image), "k_tower" (developer knobs), "k_conv3x3" (per layer), "" before fpc_load_weights */
 void *fpc_stream(fpc_engine *e);                 /* hipStream_t the engine launches on */
 
 #ifdef __cplusplus

@@ -173,7 +173,7 @@ def test_towerw_and_tower_give_identical_bits_at_hidden_128(R, blocks, monkeypat
             monkeypatch.setenv("FPC_TOWERW", w)
             eng = make_engine("gpu", R, INV_OF[R], max_games=G, max_sims=4, nn_dtype=dtype)
             eng.load_weights(weights.export_weights(m, dtype))
-            assert (eng.L.fpc_nn_kernel(eng.h) or b"").decode() == ("k_towerw" if w == "1" else "k_tower")
+            assert (eng.L.fpc_nn_kernel(eng.h) or b"").decode() == ("k_towerw" if w == "1" else "k_towerc" if R == 14 else "k_tower")
             lg = torch.empty(G, eng.A, device="cuda")
             va = torch.empty(G, device="cuda")
             for _ in range(2):

@@ -4,7 +4,7 @@
 N=$1; shift
 for i in $(seq 1 $N); do
   for L in "$@"; do
-    FPC_ENGINE_LIB=$PWD/$L python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt-policy-head --no-alt-dtype --no-dropin ${BENCH_ARGS} 2>/dev/null | tail -1 | python3 -c "
+    FPC_ENGINE_LIB=$PWD/$L python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt-policy-head --no-alt-dtype --no-dropin --no-live-traffic ${BENCH_ARGS} 2>/dev/null | tail -1 | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read()); st = d['stage_ms_per_sim_step']
 print('$L', '%.0f sims/s' % d['value'], ' '.join('%s=%.4f' % (k[:6], v) for k, v in st.items()))" || exit 1

@@ -21,7 +21,7 @@ for name in "abcdef":
         k = r['Kernel_Name'][:24]
         agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, d in agg.items():
-        if not any(t in k for t in ('k_fcw<', 'k_fc16<', 'k_tower<', 'k_fc_reduce')):
+        if not any(t in k for t in ('k_fcw<', 'k_fc16<', 'k_tower<', 'k_towerc<', 'k_fc_reduce')):
             continue
         print(name, k, {c: round(sum(v) / len(v), 1) for c, v in d.items()})
 PY

@@ -789,7 +789,11 @@ struct NN {
       if ((rc = conv(vconv, act[cur], F, nullptr, yv, 32, 24, 0))) return rc;
     }
     if (mark_fn) mark_fn(mark_ctx, 2);
+#if defined(TW_STRIP) && (TW_STRIP & 128)
+    if (false) {                 // timing-only diagnostic build: the tower alone, no policy Linear behind it
+#else
     if (logits_out) {            // null: legal-only policy head, the caller runs k_policy_gemv instead
+#endif
       FcArgs f{};
       f.X = xfc; f.Wf = fcw; f.part = fc_part; f.Kp = Kp; f.Np = Np; f.ksteps = Kp / 16; f.Mtot = Gpad;
       f.G1 = fc_G1; f.s1 = fc_s1; f.s2 = fc_s2;

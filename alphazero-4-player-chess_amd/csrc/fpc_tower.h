@@ -213,6 +213,18 @@ __device__ __forceinline__ void tw_dma_256(const unsigned char *gsrc_uniform, ui
 #ifndef TW_STAGGER
 #define TW_STAGGER 3
 #endif
+// TIMING-ONLY diagnostic builds (-DTW_STRIP=<bits>; results are wrong on purpose): take the tower apart the way
+// tools/micro/fc_stream.cpp took the Linear apart.  1: no MFMAs in the k-steps; 2: no fragment reads in the k-steps;
+// 4: no weight DMA; 8: no tap barriers; 16: no epilogue conversions / stores; 32: return behind the stem; 64: no copy-out
+// of the policy rows; 128 (fpc_nn.h): no policy Linear behind the tower (its power draw depends on what the tower wrote).
+// The product build defines nothing.
+#ifndef TW_STRIP
+#define TW_STRIP 0
+#endif
+// k_towerc: how many of the 13 row tiles the loader half (waves 0-3, which also carries the weight DMA) owns
+#ifndef TWC_LOADER_TILES
+#define TWC_LOADER_TILES 6
+#endif
 
 // NW: waves per workgroup.  4 = one wave per SIMD, wave (wm, wn) owns MT row tiles x 4 column tiles (64 output
 // channels).  8 = two waves per SIMD, each with half the register file: wave (wm, wn) owns MT row tiles x 2 column
@@ -231,9 +243,9 @@ __device__ __forceinline__ void tw_dma_256(const unsigned char *gsrc_uniform, ui
 // same order (bit-identical logits; the value head sums the same terms in another order).
 template <int DT, int MT, bool FAST, int NW, int LOAD, bool CMP = false>
 __device__ __forceinline__ void tw_body(const TowerArgs &g) {
-  static_assert(!CMP || (!FAST && NW == 8 && TW_LOADERS == 1 && MT == (LOAD == 2 ? 6 : 7)), "compact form: 8 waves, tiles 6 + 7");
+  static_assert(!CMP || (!FAST && NW == 8 && TW_LOADERS == 1 && MT == (LOAD == 2 ? TWC_LOADER_TILES : 13 - TWC_LOADER_TILES)), "compact form: 8 waves, 13 row tiles");
   constexpr int CR = 14, CZ = 16;                   // CMP: board side, zero rows in front of square 0
-  constexpr int TB0 = LOAD == 2 ? 0 : 6;           // CMP: first row tile of this wave half
+  constexpr int TB0 = LOAD == 2 ? 0 : TWC_LOADER_TILES;   // CMP: first row tile of this wave half
   constexpr int NT = NW * 64;                      // threads
   constexpr int WN = NW / 2;                       // waves along the output channels
   constexpr int CT = 8 / WN;                       // column tiles (16 channels) per wave: 4 or 2
@@ -388,7 +400,7 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
   };
   auto issue_tap = [&](int T) {   // the whole tap T -> ring slot T % 3 in one burst
     issue_bias(T);
-    if (LOAD == 0) return;
+    if (LOAD == 0 || (TW_STRIP & 4)) return;
     const unsigned char *src = g.Wt + (size_t)T * TW_TAP + lw * DMA_PER_WAVE;
     const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(TW_RING + (T % 3) * TW_TAP + lw * DMA_PER_WAVE);   // smem starts at LDS byte 0
     if (PIECES == 8) tw_dma_8k(src, dma_lane, dst);
@@ -422,6 +434,7 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
   unsigned char *const wbase = img + (rbase >> 3) * 2048 + (rbase & 7) * 16 + wn * (CT * 256) + (lane >> 5) * 128 + ((lane >> 4) & 1) * 8;
   auto epilogue = [&](auto res_c) {
     constexpr int RES = decltype(res_c)::value;      // 0: plain; 1: keep as residual (stem); 2: add the residual, keep
+    if (TW_STRIP & 16) return;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       unsigned char *dst = ((inmask >> mt) & 1u) ? wbase + mt * 4096 : dummy;
@@ -444,6 +457,7 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
   const std::integral_constant<int, 2> c2{};
   const std::integral_constant<int, 3> c3{};
   epilogue(c1);                  // stem: x_0 = relu(conv + b)
+  if (TW_STRIP & 32) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }      // timing only: prologue + stem alone
   if (STREAM) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES + LOAD) : "memory");   // tap 1 and the first quarter of tap 2 stay in flight
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();               // x_0 complete, tap 0 and layer 0's biases landed
@@ -501,20 +515,28 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
     constexpr int MODE = decltype(mode_c)::value, B = decltype(buf_c)::value, KSN = decltype(ksn_c)::value;
     constexpr bool BIAS = decltype(bias_c)::value != 0;
     constexpr int N = B ^ 1, Q = decltype(q_c)::value;
+    if (!(TW_STRIP & 2)) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) fa[N][ct] = *reinterpret_cast<const t_u32x4 *>(wslot + ct * 4096 + KSN * 512);
-    fb[N][0] = *reinterpret_cast<const t_u32x4 *>(bptr(0) + KSN * 512);
+      for (int ct = 0; ct < CT; ++ct) fa[N][ct] = *reinterpret_cast<const t_u32x4 *>(wslot + ct * 4096 + KSN * 512);
+      fb[N][0] = *reinterpret_cast<const t_u32x4 *>(bptr(0) + KSN * 512);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      if (MODE == 0) {
+      if (TW_STRIP & 1) {
+        if (BIAS) {
+#pragma unroll
+          for (int ct = 0; ct < (MODE == 0 ? CT : 1); ++ct) acc[mt][ct] = b4[ct];
+        }
+        asm volatile("" : "+v"(fa[B][0]), "+v"(fb[B][mt]));      // the fragments stay "used"
+      } else if (MODE == 0) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[mt][ct] = M16<DT>::mfma(fa[B][ct], fb[B][mt], BIAS ? b4[ct] : acc[mt][ct]);
       } else if (NW == 4 || vactive) {             // wave-uniform
         acc[mt][0] = M16<DT>::mfma(fa[B][0], fb[B][mt], BIAS ? b4[0] : acc[mt][0]);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (mt + 1 < MT) {
+      if (mt + 1 < MT && !(TW_STRIP & 2)) {
         fb[N][mt + 1] = *reinterpret_cast<const t_u32x4 *>(bptr(mt + 1) + KSN * 512);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -541,7 +563,7 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
 #pragma unroll
       for (int ct = 0; ct < (MODE == 0 ? CT : 1); ++ct) b4[ct] = *reinterpret_cast<const t_f32x4 *>(bl + ct * 16);
     }
-    if (STAG == 3) __syncthreads();                // (a staggered wave issued no DMA: nothing to wait for)
+    if (STAG == 3 && !(TW_STRIP & 8)) __syncthreads();                // (a staggered wave issued no DMA: nothing to wait for)
     kstep(mode_c, c0, c1, c1, b4, c1);             // (tap 0, k-step 0), C = bias
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
@@ -565,7 +587,7 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
         if (STREAM) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         TW_STAMP(gt, 3);
-        __syncthreads();
+        if (!(TW_STRIP & 8)) __syncthreads();
         TW_STAMP(gt, 4);
         if (STREAM) open_tap(gt + 3);
         else if (gt + 2 < total) issue_tap(gt + 2);
@@ -576,7 +598,7 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
       TW_STAMP(gt - 1, 6);
       kstep(mode_c, c1, c0, c0, b4, c0);           // k-step 3, reading (next tap, k-step 0)
       TW_STAMP(gt - 1, 7);
-      if (STAG == 3 && tap < 8) __syncthreads();
+      if (STAG == 3 && tap < 8 && !(TW_STRIP & 8)) __syncthreads();
       if (tap < 8) kstep(mode_c, c0, c1, c0, b4, c1);  // (next tap, k-step 0)
       TW_STAMP(gt - 1, 8);
     }
@@ -623,7 +645,7 @@ __device__ __forceinline__ void tw_body(const TowerArgs &g) {
   __syncthreads();
 
   // ---- heads: policy-conv rows -> Linear input (position-major), value -> tanh ---------------------------
-  {
+  if (!(TW_STRIP & 64)) {
     const int cpr = g.A_ch / 8;                     // 16-byte chunks per position
     for (int c = tid; c < (CMP ? CR * CR : g.PP) * 16; c += NT) {
       const int j = c & 15;
@@ -659,11 +681,11 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_tower(TowerArgs g) {
   }
 }
 
-// the compact form at 14x14 (CMP): loaders = row tiles 0..5, staggered half = row tiles 6..12
+// the compact form at 14x14 (CMP): loaders = row tiles 0 .. TWC_LOADER_TILES - 1, staggered half = the rest of the 13
 template <int DT>
 __global__ void __launch_bounds__(512, 2) k_towerc(TowerArgs g) {
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) tw_body<DT, 6, false, 8, 2, true>(g);
-  else tw_body<DT, 7, false, 8, 0, true>(g);
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) tw_body<DT, TWC_LOADER_TILES, false, 8, 2, true>(g);
+  else tw_body<DT, 13 - TWC_LOADER_TILES, false, 8, 0, true>(g);
 }
 
 // weights [taps][128 rows][cin] 16-bit row-major -> per tap the LDS image (tw_lay with cin/8 chunks per row)

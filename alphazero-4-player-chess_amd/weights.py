@@ -42,15 +42,27 @@ def _conv_section(w, b, cin_pad, cout_pad, dtype):
 
 
 # Fragment order / block tile of the policy Linear: 2 = 16x16x32 fragments over 384-column groups (k_fcw: 256 x 384 block
-# tiles, one round of blocks; the default where its one-round K-split exists: the 14x14 board), 1 = the same fragment order
-# over 256-column groups (k_fc16, the default elsewhere).  FPC_FC_LAYOUT forces one.  (0, the 32x32x16 order of k_fc, was
-# retired in round 5 together with blob version 2.)
+# tiles, ONE round of blocks; the default wherever its one-round K-split exists on a 256-CU part: every board of 8..14
+# a side), 1 = the same fragment order over 256-column groups (k_fc16: long and short blocks in two rounds; the fallback).
+# FPC_FC_LAYOUT forces one.  (0, the 32x32x16 order of k_fc, was retired in round 5 together with blob version 2.)
 FC_LAYOUT = int(os.environ["FPC_FC_LAYOUT"]) if "FPC_FC_LAYOUT" in os.environ else None
 
 
-def default_fc_layout(R):
-    return FC_LAYOUT if FC_LAYOUT is not None else (2 if R == 14 else 1)
+def fcw_split(R, cus=256):
+    """K-splits k_fcw would use for an R x R board on a part with `cus` CUs (csrc/fpc_nn.h: plan_fcw), 0 if none"""
+    A = (8 * R + 8) * R * R
+    groups, stages = (A + 383) // 384, ((A + 511) // 512 * 512) // 64
+    best = 0
+    for sk in range(1, 9):
+        if groups * sk <= cus and stages % sk == 0 and stages // sk >= 4:
+            best = sk
+    return best
 
+
+def default_fc_layout(R):
+    if FC_LAYOUT is not None:
+        return FC_LAYOUT
+    return 2 if fcw_split(R) else 1
 
 
 def export_weights(model, dtype=0, fc_layout=None):

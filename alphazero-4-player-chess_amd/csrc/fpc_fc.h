@@ -1,8 +1,9 @@
 // fpc_fc.h -- the policy Linear (net.py:25: A -> A, 553 M weights at 14x14 = 1.1 GB in 16 bit) as a weight-streaming
 // GEMM for M = 256 rows: every weight byte is used once per forward, so the kernels are bound by the HBM stream
 // (1.11 GB per launch; 283 GFLOP ride on it) and by whatever else travels the same L1 / L2 / LDS-DMA path.
-//   k_fcw   (round 5; blob fc_layout 2; the default at 14x14): 256 x 384 block tiles, one round of blocks -- see below.
-//   k_fc16  (round 3; fc_layout 1; the other board sizes): 256 x 256 block tiles, long and short blocks in two rounds.
+//   k_fcw   (round 5; blob fc_layout 2; the default wherever its one-round K-split exists: every board of 8..14 a side on
+//           a 256-CU part): 256 x 384 block tiles, one round of blocks -- see below.
+//   k_fc16  (round 3; fc_layout 1; the fallback): 256 x 256 block tiles, long and short blocks in two rounds.
 //   (k_fc, rounds 1-4: the same on v_mfma_f32_32x32x16 with its own fragment order -- retired in round 5; what it
 //   established is kept in the notes below.)
 // Common to both:
@@ -201,7 +202,7 @@ __global__ void __launch_bounds__(FC_THREADS, 1) k_fc16(FcArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_fcw (round 5): the same Linear on 256 x 384 block tiles -- the default at 14x14 (blob header fc_layout = 2).
+// k_fcw (round 5): the same Linear on 256 x 384 block tiles -- the default (blob header fc_layout = 2).
 //
 // Why.  tools/micro/fc_stream.cpp replays k_fc16's memory pattern with the arithmetic taken out or left in (register
 // operands, no LDS reads) and reproduces its 250 us; taken apart on one box: the weight stream alone 168 us (6.6 TB/s, the

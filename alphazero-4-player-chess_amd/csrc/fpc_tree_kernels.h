@@ -1290,8 +1290,21 @@ __device__ inline void select_game(WaveLds &s, const DevCfg &c, const Tree &t, i
       int Nc = 0, cc0 = -1, cnc = 0, cslot = -1, cmv = 0xffff;
       if (i < nc) {
         Nc = t.N[nb + c0 + i];
-        const double Wc = t.W[nb + c0 + i];
-        const double Pc = (double)t.P[nb + c0 + i];
+        double Wc = t.W[nb + c0 + i];
+        double Pc = (double)t.P[nb + c0 + i];
+#ifdef FPC_TREE_LDS_STAGE
+        // A/B arm only (north_star: "per-game node N/W/P arrays staged in LDS"): the level's children pass through LDS
+        // before the PUCT arithmetic reads them -- one more dependent round trip per level, no reuse to pay for it
+        // (a level is read exactly once per simulation).  Measured in profiles/r05/ab_summary.md; the product keeps them in registers.
+        {
+          int *sN = reinterpret_cast<int *>(&s.scr[0][0][0]);
+          double *sW = reinterpret_cast<double *>(&s.scr[0][0][0]) + 64;
+          float *sP = reinterpret_cast<float *>(&s.scr[0][0][0]) + 64 + 128 + 64;
+          sN[lane] = Nc; sW[lane] = Wc; sP[lane] = (float)Pc;
+          __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the stores are in LDS
+          Nc = *const_cast<volatile int *>(&sN[lane]); Wc = *const_cast<volatile double *>(&sW[lane]); Pc = (double)*const_cast<volatile float *>(&sP[lane]);
+        }
+#endif
         cc0 = t.child0[nb + c0 + i];
         cnc = t.nch[nb + c0 + i];
         cslot = t.bslot[nb + c0 + i];

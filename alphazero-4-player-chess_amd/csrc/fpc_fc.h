@@ -349,6 +349,9 @@ __global__ void __launch_bounds__(FC_THREADS, 1) k_fcw(FcArgs g) {
     kstep(c1, c0, s);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail pieces: nothing may still target LDS at exit
+  // The MFMAs above are inline asm: hipcc's hazard recogniser does not see them, so the wait states the ISA asks for between
+  // an 8-pass MFMA writing a register and a store / v_accvgpr_read reading it (11) are spelt out here, once, behind the loop.
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
 
   float *out = g.part + ((long)id * g.Mtot + mrow0) * FCW_COLS;
 #pragma unroll

@@ -700,7 +700,7 @@ def live_traffic(R, blocks, hidden, G, dt):
             d = os.path.join(tmp, counter)
             r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
                                 sys.executable, os.path.join(HERE, "tools", "nn_only.py"), "3"],
-                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=100)
             fs = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
             if r.returncode != 0 or not fs:
                 return None

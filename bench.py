@@ -698,11 +698,22 @@ def live_traffic(R, blocks, hidden, G, dt):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
-            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
-                                sys.executable, os.path.join(HERE, "tools", "nn_only.py"), "3"],
-                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=100)
+            # its own process group: on a timeout the profiler AND the python it started are ended (exactly that group)
+            pr = subprocess.Popen([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
+                                   sys.executable, os.path.join(HERE, "tools", "nn_only.py"), "3"],
+                                  cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=100)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.wait()
+                return None
             fs = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
-            if r.returncode != 0 or not fs:
+            if rc != 0 or not fs:
                 return None
             agg = collections.defaultdict(list)
             for row in csv.DictReader(open(fs[0])):

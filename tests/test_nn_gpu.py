@@ -650,3 +650,38 @@ def test_native_search_with_dropped_roots_and_weight_reload():
         assert sd[3] < sims and sd[-1] < sims and sd[3] == sd[-1]          # the Q5 roots were dropped early
         assert max(sd) == sims                                              # ... next to games that ran to the end
     assert (res[False]["visits"] == res[True]["visits"]).all() and (res[False]["sims_done"] == res[True]["sims_done"]).all()
+
+
+def test_weight_blob_header_is_checked():
+    """fpc_load_weights refuses, with a message that says why: a version-2 blob (rounds 1-2: the retired 32x32x16
+    policy-Linear order -- an engine must never run k_fcw / k_fc16 on such weights), an unknown fc_layout, a blob for
+    another operand type, a truncated blob.  The engine stays usable: the right blob loads afterwards."""
+    import struct
+    import torch
+    import weights
+    R, dtype = 8, 1
+    m = _model(R, 2, 64, seed=4)
+    blob = weights.export_weights(m, dtype)
+    magic, version, r, F, nb, dt, a_ch, Np, Kp, layout = struct.unpack_from("<4s9i", blob, 0)
+    assert magic == b"FPCW" and version == 3 and layout == 2 and Np % 384 == 0 and r == R
+    eng = make_engine("gpu", R, INV_OF[R], max_games=8, max_sims=4, nn_dtype=dtype)
+
+    def patched(**kw):
+        f = {"version": version, "dtype": dt, "layout": layout}
+        f.update(kw)
+        return struct.pack("<4s9i", magic, f["version"], r, F, nb, f["dtype"], a_ch, Np, Kp, f["layout"]) + blob[40:]
+
+    for bad, words in ((patched(version=2), "version"), (patched(layout=0), "layout"), (patched(layout=7), "layout"),
+                       (patched(dtype=0), "dtype"), (blob[: len(blob) // 2], "truncated")):
+        with pytest.raises(RuntimeError) as ei:
+            eng.load_weights(bad)
+        assert words in str(ei.value), (words, str(ei.value))
+    eng.load_weights(blob)
+    x = (torch.rand(8, 24, R, R, generator=torch.Generator().manual_seed(1)) < 0.1).float().cuda()
+    lg = torch.empty(8, eng.A, device="cuda"); va = torch.empty(8, device="cuda")
+    eng.nn_forward(x.data_ptr(), 8, lg.data_ptr(), va.data_ptr())
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref_l, _ = m(x.cpu())
+    assert np.abs(lg.cpu().numpy() - ref_l.numpy()).max() < 1e-3
+    eng.close()

@@ -4,6 +4,7 @@
 # 2. PMC passes over the network forward (tools/pmc_nn.sh; separate --pmc passes, no trace domains mixed in)
 # 3. configs[3] (ResNet(20,256), 800 sims, fp16) and the 8x8 literal-snapshot size: bench lines + kernel stats
 # 4. power / clock samples during a bench run
+# 5. (round 5) the sustained-MFMA and policy-Linear memory-pattern micro-benchmarks
 TAG=${1:-rXX}
 PART=${2:-AB}      # A: default stats + PMC passes (both networks); B: configs[3] / 8x8 / arena / memory-side PMC / power / default run
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -39,6 +40,11 @@ bash tools/pmc_fc_mem.sh > gpurun_out/$TAG/pmc_fc_mem.log 2>&1; tail -12 gpurun_
 for p in a b c d e f; do cp gpurun_out/pmcm_$p/*/*counter_collection.csv gpurun_out/$TAG/pmcm_$p.csv 2>/dev/null; done
 bash tools/power_probe.sh --no-alt-dtype > gpurun_out/$TAG/power_probe.log 2>&1; cp gpurun_out/power_samples.txt gpurun_out/$TAG/power_samples.txt; tail -3 gpurun_out/$TAG/power_probe.log | cut -c1-300
 python3 bench.py > gpurun_out/$TAG/default_run.json 2> gpurun_out/$TAG/default_run.err; cut -c1-200 gpurun_out/$TAG/default_run.json
+# round 5: the micro-benchmarks DESIGN.md 4.2 / 9 quote (build here if the binaries did not travel with the snapshot)
+[ -x tools/micro/fc_stream ] && [ -x tools/micro/mfma_sustained ] || make -s -C tools/micro fc_stream mfma_sustained
+timeout -k 10 120 tools/micro/mfma_sustained 1.0 > gpurun_out/$TAG/mfma_sustained.log 2>&1; cat gpurun_out/$TAG/mfma_sustained.log | cut -c1-200
+timeout -k 10 180 tools/micro/fc_stream 300 0 > gpurun_out/$TAG/fc_stream_decomp_layout.log 2>&1; head -6 gpurun_out/$TAG/fc_stream_decomp_layout.log
+timeout -k 10 180 tools/micro/fc_stream 300 4 > gpurun_out/$TAG/fc_stream_wide_tile.log 2>&1; head -12 gpurun_out/$TAG/fc_stream_wide_tile.log
 # the N = 2 launcher path on the one GPU of this box (gloo): rank pinning, host_ms_per_ply, ranks_seen
 python3 bench.py --gpus 2 --rehearse-one-gpu --backend gloo --steps 3 --warmup 1 --no-cpu-baseline --no-alt-dtype --no-alt-policy-head --no-dropin 2> gpurun_out/$TAG/bench_2rank_rehearsal.err | grep "^{" > gpurun_out/$TAG/bench_2rank_rehearsal.json; cut -c1-200 gpurun_out/$TAG/bench_2rank_rehearsal.json   # (gloo prints a connection banner on stdout)
 
